@@ -1,0 +1,132 @@
+/* nngp_hip.h -- C ABI of libnngp_hip.so, the MI355X (gfx950) NNGP/NTK hot path.
+ *
+ * The reference (Kangfei/NNGP-src) has no FFI: its hot path is three neural-tangents calls made
+ * from Python.  This header is therefore the boundary a reference
+ * maintainer would bind with ctypes (INTEGRATION.md shows the stub); each entry point cites the
+ * reference call it replaces.  Plain C types only -- no torch/HIP types in the signatures.
+ *
+ * Conventions
+ *   - every pointer named x*, y, mean, var*, out* is a DEVICE pointer (HBM) unless it says "host";
+ *   - matrices are row-major; inputs are float64 like the reference (train.py:24, estimator.py:12);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return value 0 = success, <0 = error (nngp_last_error() holds a thread-local message);
+ *   - entry points are re-entrant across models; one model must be driven from one stream at a time.
+ */
+#ifndef NNGP_HIP_H
+#define NNGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNGP_ABI_VERSION 1
+#define NNGP_GET_NNGP 1 /* get='nngp' */
+#define NNGP_GET_NTK 2  /* get='ntk'  */
+#define NNGP_MAX_DENSE 16
+
+#define NNGP_DTYPE_F32 0
+#define NNGP_DTYPE_F64 1
+
+#define NNGP_COV_NONE 0 /* compute_cov=False                                  */
+#define NNGP_COV_DIAG 1 /* only diag(cov): all the reference consumes (train.py:180, estimator.py:55) */
+#define NNGP_COV_FULL 2 /* compute_cov=True: the full M x M covariance        */
+
+/* Architecture of stax.serial(Dense, (Relu, Dense) x (n_dense-1)); the widths (512, 1) do not enter
+ * the closed-form kernel.  Reference: train.py:161-164, estimator.py:27-30 (n_dense = 2, W_std = 1,
+ * b_std = 0). */
+typedef struct nngp_arch {
+    int32_t n_dense;
+    int32_t reserved;
+    double w_std[NNGP_MAX_DENSE];
+    double b_std[NNGP_MAX_DENSE];
+} nngp_arch;
+
+/* Fit diagnostics (host struct filled by nngp_model_info). */
+typedef struct nngp_fit_info {
+    double reg;            /* diag_reg * trace(K)/N actually added (train.py:171-172 semantics)      */
+    double trace_mean;     /* trace(K)/N                                                            */
+    double rel_residual;   /* |y - (K + reg I) alpha|_2 / |y|_2 after refinement (float64 residual)  */
+    int32_t refine_iters;  /* preconditioned-CG iterations used (max over output columns)            */
+    int32_t clamped_pivots;/* pivots the float32 factorisation had to clamp (preconditioner only)    */
+    int64_t n;             /* training rows                                                          */
+    int64_t n_padded;      /* leading dimension of the device matrices                               */
+} nngp_fit_info;
+
+typedef struct nngp_model nngp_model;
+
+int nngp_version(void);
+const char* nngp_last_error(void);
+
+/* ---- a1: kernel_fn(x1, x2, get) ---------------------------------------------------------------
+ * Replaces the closure returned by stax.serial(...) (train.py:161-164; estimator.py:27-30).
+ * x1: [n1, d] f64; x2: [n2, d] f64 or NULL (symmetric, x2 = x1, n2 ignored).
+ * Writes rows [row_begin, row_end) of the n1 x n2 kernel (row-block shard: the slot
+ * nt.batch(device_count>0) would fill, train.py:166-168); pass 0, n1 for everything.
+ * out_nngp / out_ntk: f32 or f64 (out_dtype) matrices with leading dimension ld, either may be NULL;
+ * element (i, j) is written at out[i * ld + j] (i is the global row).                            */
+int nngp_kernel_build(const double* x1, int64_t n1, const double* x2, int64_t n2, int32_t d,
+                      const nngp_arch* arch, int32_t out_dtype, void* out_nngp, void* out_ntk,
+                      int64_t ld, int64_t row_begin, int64_t row_end, void* stream);
+
+/* K(x, x) and Theta(x, x) per row (closed form from |x|^2/d); either output may be NULL. */
+int nngp_kernel_diag(const double* x, int64_t n, int32_t d, const nngp_arch* arch,
+                     double* diag_nngp, double* diag_ntk, void* stream);
+
+/* ---- a3: gradient_descent_mse_ensemble(kernel_fn, X, Y, diag_reg) -----------------------------
+ * Replaces nt.predict.gradient_descent_mse_ensemble (train.py:171-172; estimator.py:34-35).
+ * nngp_model_create allocates every device buffer the model will need for up to n_cap training
+ * rows and m_cap test rows (no allocation happens inside fit/predict unless m > m_cap).
+ * get: NNGP_GET_NNGP or NNGP_GET_NTK (the posterior for `get`); ny: columns of Y (reference: 1).   */
+int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d, int32_t ny,
+                      const nngp_arch* arch, int32_t get, double diag_reg,
+                      int32_t diag_reg_absolute_scale);
+int nngp_model_destroy(nngp_model* m);
+
+/* Whole fit = set_train + build_rows(0, n) + factor + solve. */
+int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, void* stream);
+
+/* Stage-level entry points (bench.py times them; the multi-GPU path shards build_rows):
+ *   set_train : copy X [n, d], Y [n, ny]; row norms, closed-form diagonal, regulariser
+ *   build_rows: rows [row_begin, row_end) of the float64 train-train kernel (all columns);
+ *               (0, n) takes the symmetric path (lower tiles computed once, mirrored)
+ *   factor    : A32 = float32(K) + reg I, blocked lower Cholesky on float32 MFMA, in place
+ *   solve     : alpha = (K + reg I)^-1 Y by CG on the float64 kernel, preconditioned by the
+ *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-12)       */
+int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_t n, void* stream);
+int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, void* stream);
+int nngp_model_factor(nngp_model* m, void* stream);
+int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream);
+
+/* The float64 train-train kernel buffer (device pointer, leading dimension in elements) so the host
+ * can all-gather row blocks over RCCL between build_rows and factor. */
+int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld);
+int nngp_model_info(nngp_model* m, nngp_fit_info* info /* host */);
+/* alpha = (K + reg I)^-1 Y, [n, ny] f64, copied to a device buffer. */
+int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
+
+/* ---- a4: predict_fn(x_test, get, compute_cov) --------------------------------------------------
+ * Replaces predict_fn(x_test=..., get=..., compute_cov=True) (train.py:157-158; estimator.py:66-67).
+ * x_test: [mt, d] f64, or NULL for x_test=None (predict on the training rows, estimator.py:37-40).
+ * mean: [mt, ny] f64.  cov_mode DIAG: var_or_cov is [mt] f64; FULL: [mt, mt] f64; NONE: ignored.   */
+int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode,
+                       double* mean, double* var_or_cov, void* stream);
+
+/* ---- building blocks exported for parity tests and the integration notes ----------------------
+ * Blocked lower Cholesky of a float32 matrix in place (n multiple of 128, ld >= n).  dinv: workspace of
+ * (n/128) * 128*128 floats receiving the inverses of the diagonal blocks.  clamped: device int32.   */
+int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream);
+/* C[M,N] = beta*C + alpha * A[M,K] B[N,K]^T on float32 MFMA (all of M, N, K multiples of 128).
+ * lower_only != 0: only tiles on or below the diagonal are touched (SYRK-style, M == N).            */
+int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
+                     int64_t m, int64_t n, int64_t k, float alpha, float beta, int32_t lower_only,
+                     void* stream);
+/* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
+int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,
+                      int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNGP_HIP_H */

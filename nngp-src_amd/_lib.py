@@ -1,0 +1,127 @@
+"""ctypes binding of ``libnngp_hip.so`` (C ABI in ``include/nngp_hip.h``).
+
+There is no CPU fallback: every compute entry point raises if the HIP library is missing or no
+MI355X is visible.  PyTorch is used only as the owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnngp_hip.so")
+
+GET_NNGP, GET_NTK = 1, 2
+DTYPE_F32, DTYPE_F64 = 0, 1
+COV_NONE, COV_DIAG, COV_FULL = 0, 1, 2
+MAX_DENSE = 16
+
+# every symbol include/nngp_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "nngp_version", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
+    "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
+    "nngp_model_factor", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
+    "nngp_model_alpha", "nngp_model_predict", "nngp_potrf_f32", "nngp_gemm_nt_f32", "nngp_trsm_rlt_f32",
+)
+
+
+class NngpArch(ctypes.Structure):
+    _fields_ = [("n_dense", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("w_std", ctypes.c_double * MAX_DENSE), ("b_std", ctypes.c_double * MAX_DENSE)]
+
+
+class NngpFitInfo(ctypes.Structure):
+    _fields_ = [("reg", ctypes.c_double), ("trace_mean", ctypes.c_double), ("rel_residual", ctypes.c_double),
+                ("refine_iters", ctypes.c_int32), ("clamped_pivots", ctypes.c_int32),
+                ("n", ctypes.c_int64), ("n_padded", ctypes.c_int64)]
+
+
+class NngpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libnngp_hip.so (no GPU needed to load; compute calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NngpError(
+            "libnngp_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nngp-src_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+    archp = ctypes.POINTER(NngpArch)
+    lib.nngp_version.restype = ctypes.c_int
+    lib.nngp_last_error.restype = ctypes.c_char_p
+    lib.nngp_kernel_build.argtypes = [vp, i64, vp, i64, i32, archp, i32, vp, vp, i64, i64, i64, vp]
+    lib.nngp_kernel_diag.argtypes = [vp, i64, i32, archp, vp, vp, vp]
+    lib.nngp_model_create.argtypes = [ctypes.POINTER(vp), i64, i64, i32, i32, archp, i32, dbl, i32]
+    lib.nngp_model_destroy.argtypes = [vp]
+    lib.nngp_model_fit.argtypes = [vp, vp, vp, i64, vp]
+    lib.nngp_model_set_train.argtypes = [vp, vp, vp, i64, vp]
+    lib.nngp_model_build_rows.argtypes = [vp, i64, i64, vp]
+    lib.nngp_model_factor.argtypes = [vp, vp]
+    lib.nngp_model_solve.argtypes = [vp, i32, dbl, vp]
+    lib.nngp_model_kernel_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.nngp_model_info.argtypes = [vp, ctypes.POINTER(NngpFitInfo)]
+    lib.nngp_model_alpha.argtypes = [vp, vp, vp]
+    lib.nngp_model_predict.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]
+    lib.nngp_gemm_nt_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float, i32, vp]
+    lib.nngp_trsm_rlt_f32.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp]
+    for name in ABI_SYMBOLS:
+        if name != "nngp_last_error":
+            getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().nngp_last_error()
+        raise NngpError("libnngp_hip: rc=%d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))
+
+
+def make_arch(w_std, b_std) -> NngpArch:
+    w_std = [float(v) for v in w_std]
+    b_std = [float(v) for v in b_std]
+    if len(w_std) != len(b_std) or not 1 <= len(w_std) <= MAX_DENSE:
+        raise ValueError("architecture must have 1..%d Dense layers" % MAX_DENSE)
+    arch = NngpArch()
+    arch.n_dense = len(w_std)
+    for i, (w, b) in enumerate(zip(w_std, b_std)):
+        arch.w_std[i] = w
+        arch.b_std[i] = b
+    return arch
+
+
+def require_gpu():
+    """The torch device used for HBM buffers; raises (never falls back) when no GPU is present."""
+    import torch
+    if not torch.cuda.is_available():
+        raise NngpError("no MI355X/ROCm device visible: the NNGP hot path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device_f64(a, device=None):
+    """numpy / torch array -> contiguous float64 device tensor."""
+    import torch
+    device = device or require_gpu()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float64).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())

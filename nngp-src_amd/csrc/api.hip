@@ -1,0 +1,442 @@
+// C-ABI entry points of libnngp_hip.so (include/nngp_hip.h) and the model object that owns the
+// device buffers of one GP fit.  Mirrors the three nested reference interfaces of SURVEY.md 8b:
+//   kernel_fn(x1, x2, get)                                  -> nngp_kernel_build
+//   gradient_descent_mse_ensemble(kernel_fn, X, Y, diag_reg) -> nngp_model_create / _fit
+//   predict_fn(x_test, get, compute_cov)                    -> nngp_model_predict
+#include <stdarg.h>
+
+#include <cmath>
+#include <new>
+
+#include "common.h"
+
+namespace nngp {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int make_arch_dev(const nngp_arch* arch, ArchDev* out) {
+    NNGP_REQUIRE(arch != nullptr, "arch is NULL");
+    NNGP_REQUIRE(arch->n_dense >= 1 && arch->n_dense <= NNGP_MAX_DENSE, "arch.n_dense must be in [1, %d] (got %d)",
+                 NNGP_MAX_DENSE, arch->n_dense);
+    out->n_dense = arch->n_dense;
+    for (int l = 0; l < NNGP_MAX_DENSE; ++l) {
+        out->w2[l] = l < arch->n_dense ? arch->w_std[l] * arch->w_std[l] : 0.0;
+        out->b2[l] = l < arch->n_dense ? arch->b_std[l] * arch->b_std[l] : 0.0;
+    }
+    return 0;
+}
+
+template <typename T>
+static int dev_alloc(T** p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) return 0;
+    NNGP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)count));
+    return 0;
+}
+
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace nngp
+
+using namespace nngp;
+
+struct nngp_model {
+    int64_t n_cap = 0, np_cap = 0, m_cap = 0;
+    int d = 0, ny = 1, get = NNGP_GET_NNGP;
+    ArchDev arch{};
+    double diag_reg = 1e-3;
+    int absolute = 0;
+
+    int64_t n = 0, np = 0;
+    bool have_train = false, built = false, factored = false, solved = false;
+
+    // training-side buffers
+    double* x = nullptr;      // [n_cap, d]
+    double* y = nullptr;      // [n_cap, ny]
+    double* q = nullptr;      // [n_cap] |x|^2/d
+    double* kdiag = nullptr;  // [n_cap] K(x,x) of the `get` kernel
+    double* k64 = nullptr;    // [np_cap, np_cap] float64 train-train kernel (`get`), ld = np
+    float* a32 = nullptr;     // [np_cap, np_cap] float32 A = K + reg I -> L (lower), ld = np
+    float* dinv = nullptr;    // [np_cap/128][128*128] inverted diagonal blocks of L
+    int32_t* clamped = nullptr;
+    double* alpha = nullptr;  // [n_cap, ny]
+    PcgWork pcg{};
+
+    // predict-side buffers (grown on demand when m > m_cap)
+    double* xt_q = nullptr;      // [m_cap]
+    double* tt_diag = nullptr;   // [m_cap] nngp K(x_t, x_t)
+    double* ktd64 = nullptr;     // [m_cap, np_cap] float64 cross kernel
+    float* b32 = nullptr;        // [mp_cap, np_cap] float32 RHS of the triangular solve
+    int64_t ktd_cap = 0;         // capacity (rows) of ktd64
+    int64_t full_cap = 0;        // capacity (rows) of the full-covariance buffers
+    double* ktt64 = nullptr;     // [full_cap, full_cap]
+    float* vvt32 = nullptr;      // [fullp, fullp]
+
+    double reg = 0.0, trace_mean = 0.0, relres = 0.0;
+    int iters = 0;
+
+    ~nngp_model() {
+        dev_free(x); dev_free(y); dev_free(q); dev_free(kdiag); dev_free(k64); dev_free(a32); dev_free(dinv);
+        dev_free(clamped); dev_free(alpha);
+        dev_free(pcg.r); dev_free(pcg.z); dev_free(pcg.p); dev_free(pcg.q); dev_free(pcg.xcol); dev_free(pcg.bcol);
+        dev_free(pcg.f32a); dev_free(pcg.f32b); dev_free(pcg.f32c); dev_free(pcg.scal);
+        if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
+        dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(ktt64); dev_free(vvt32);
+    }
+};
+
+namespace {
+
+__global__ __launch_bounds__(1024) void k_sum(const double* __restrict__ a, int64_t n, double* out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *out = t;
+    }
+}
+
+int ensure_predict_capacity(nngp_model* m, int64_t mt, bool need_ktd) {
+    if (mt > m->m_cap || m->b32 == nullptr) {
+        const int64_t cap = mt > m->m_cap ? mt : m->m_cap;
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(m->xt_q); dev_free(m->tt_diag); dev_free(m->b32);
+        NNGP_TRY(dev_alloc(&m->xt_q, cap));
+        NNGP_TRY(dev_alloc(&m->tt_diag, cap));
+        NNGP_TRY(dev_alloc(&m->b32, round_up(cap, TB) * m->np_cap));
+        m->m_cap = cap;
+    }
+    if (need_ktd && mt > m->ktd_cap) {
+        const int64_t cap = mt > m->m_cap ? mt : m->m_cap;
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(m->ktd64);
+        NNGP_TRY(dev_alloc(&m->ktd64, cap * m->np_cap));
+        m->ktd_cap = cap;
+    }
+    return 0;
+}
+
+int ensure_full_cov_capacity(nngp_model* m, int64_t mt) {
+    if (mt > m->full_cap) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(m->ktt64); dev_free(m->vvt32);
+        const int64_t mp = round_up(mt, TB);
+        NNGP_TRY(dev_alloc(&m->ktt64, mt * mp));
+        NNGP_TRY(dev_alloc(&m->vvt32, mp * mp));
+        m->full_cap = mt;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nngp_version(void) { return NNGP_ABI_VERSION; }
+
+const char* nngp_last_error(void) { return g_err; }
+
+int nngp_kernel_diag(const double* x, int64_t n, int32_t d, const nngp_arch* arch, double* diag_nngp,
+                     double* diag_ntk, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ArchDev ad;
+    NNGP_TRY(make_arch_dev(arch, &ad));
+    NNGP_REQUIRE(x != nullptr && n >= 0 && d > 0, "kernel_diag: bad arguments");
+    if (n == 0) return 0;
+    double* q = nullptr;
+    NNGP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&q), sizeof(double) * n, s));
+    int rc = launch_row_sqnorm(x, n, d, q, s);
+    if (rc == 0) rc = launch_diag_from_q(q, n, ad, diag_nngp, diag_ntk, s);
+    (void)hipFreeAsync(q, s);
+    return rc;
+}
+
+int nngp_kernel_build(const double* x1, int64_t n1, const double* x2, int64_t n2, int32_t d, const nngp_arch* arch,
+                      int32_t out_dtype, void* out_nngp, void* out_ntk, int64_t ld, int64_t row_begin,
+                      int64_t row_end, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ArchDev ad;
+    NNGP_TRY(make_arch_dev(arch, &ad));
+    NNGP_REQUIRE(x1 != nullptr && n1 >= 0 && d > 0, "kernel_build: bad x1/n1/d");
+    const bool sym = (x2 == nullptr);
+    if (sym) n2 = n1;
+    NNGP_REQUIRE(n2 >= 0 && ld >= n2, "kernel_build: ld (%lld) < n2 (%lld)", (long long)ld, (long long)n2);
+    NNGP_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n1, "kernel_build: bad row range");
+    NNGP_REQUIRE(out_dtype == NNGP_DTYPE_F32 || out_dtype == NNGP_DTYPE_F64, "kernel_build: bad out_dtype");
+    NNGP_REQUIRE(out_nngp != nullptr || out_ntk != nullptr, "kernel_build: no output requested");
+    if (n1 == 0 || n2 == 0 || row_begin == row_end) return 0;
+
+    double *q1 = nullptr, *q2 = nullptr;
+    NNGP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&q1), sizeof(double) * n1, s));
+    int rc = launch_row_sqnorm(x1, n1, d, q1, s);
+    if (!sym && rc == 0) {
+        if (hipMallocAsync(reinterpret_cast<void**>(&q2), sizeof(double) * n2, s) != hipSuccess) {
+            set_error("kernel_build: hipMallocAsync failed");
+            rc = -1;
+        } else {
+            rc = launch_row_sqnorm(x2, n2, d, q2, s);
+        }
+    }
+    if (rc == 0) {
+        BuildArgs a{};
+        a.x1 = x1; a.x2 = sym ? x1 : x2; a.q1 = q1; a.q2 = sym ? q1 : q2;
+        a.n1 = n1; a.n2 = n2; a.d = d;
+        a.row_begin = row_begin; a.row_end = row_end;
+        a.sym = (sym && row_begin == 0 && row_end == n1) ? 1 : 0;
+        a.ld64 = a.ld32 = ld;
+        if (out_dtype == NNGP_DTYPE_F64) {
+            a.nngp64 = (double*)out_nngp; a.ntk64 = (double*)out_ntk;
+        } else {
+            a.nngp32 = (float*)out_nngp; a.ntk32 = (float*)out_ntk;
+        }
+        rc = launch_kernel_build(a, ad, s);
+    }
+    if (q1) (void)hipFreeAsync(q1, s);
+    if (q2) (void)hipFreeAsync(q2, s);
+    return rc;
+}
+
+int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d, int32_t ny, const nngp_arch* arch,
+                      int32_t get, double diag_reg, int32_t diag_reg_absolute_scale) {
+    NNGP_REQUIRE(out != nullptr, "model_create: out is NULL");
+    *out = nullptr;
+    NNGP_REQUIRE(n_cap > 0 && d > 0 && ny > 0 && m_cap >= 0, "model_create: bad sizes");
+    NNGP_REQUIRE(get == NNGP_GET_NNGP || get == NNGP_GET_NTK, "model_create: get must be NNGP_GET_NNGP or NNGP_GET_NTK");
+    NNGP_REQUIRE(diag_reg >= 0.0, "model_create: diag_reg must be >= 0");
+    nngp_model* m = new (std::nothrow) nngp_model();
+    NNGP_REQUIRE(m != nullptr, "model_create: out of host memory");
+    int rc = make_arch_dev(arch, &m->arch);
+    if (rc != 0) {
+        delete m;
+        return rc;
+    }
+    m->n_cap = n_cap; m->np_cap = round_up(n_cap, TB); m->m_cap = 0;
+    m->d = d; m->ny = ny; m->get = get; m->diag_reg = diag_reg; m->absolute = diag_reg_absolute_scale;
+    const int64_t np = m->np_cap;
+    auto A = [&](int r) { if (rc == 0) rc = r; };
+    A(dev_alloc(&m->x, n_cap * d)); A(dev_alloc(&m->y, n_cap * ny)); A(dev_alloc(&m->q, n_cap));
+    A(dev_alloc(&m->kdiag, n_cap)); A(dev_alloc(&m->k64, np * np)); A(dev_alloc(&m->a32, np * np));
+    A(dev_alloc(&m->dinv, (np / TB) * TB * TB)); A(dev_alloc(&m->clamped, 1)); A(dev_alloc(&m->alpha, n_cap * ny));
+    A(dev_alloc(&m->pcg.r, np)); A(dev_alloc(&m->pcg.z, np)); A(dev_alloc(&m->pcg.p, np)); A(dev_alloc(&m->pcg.q, np));
+    A(dev_alloc(&m->pcg.xcol, np)); A(dev_alloc(&m->pcg.bcol, np));
+    A(dev_alloc(&m->pcg.f32a, np)); A(dev_alloc(&m->pcg.f32b, np)); A(dev_alloc(&m->pcg.f32c, np));
+    A(dev_alloc(&m->pcg.scal, 8));
+    if (rc == 0 && hipHostMalloc(reinterpret_cast<void**>(&m->pcg.host_scal), sizeof(double) * 8) != hipSuccess) {
+        set_error("model_create: hipHostMalloc failed");
+        rc = -1;
+    }
+    if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
+    if (rc != 0) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+int nngp_model_destroy(nngp_model* m) {
+    if (m) {
+        (void)hipDeviceSynchronize();
+        delete m;
+    }
+    return 0;
+}
+
+int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_t n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && x != nullptr && y != nullptr, "set_train: NULL argument");
+    NNGP_REQUIRE(n > 0 && n <= m->n_cap, "set_train: n=%lld outside (0, n_cap=%lld]", (long long)n, (long long)m->n_cap);
+    m->n = n;
+    m->np = round_up(n, TB);
+    m->built = m->factored = m->solved = false;
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->x, x, sizeof(double) * n * m->d, hipMemcpyDeviceToDevice, s));
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->y, y, sizeof(double) * n * m->ny, hipMemcpyDeviceToDevice, s));
+    NNGP_TRY(launch_row_sqnorm(m->x, n, m->d, m->q, s));
+    NNGP_TRY(launch_diag_from_q(m->q, n, m->arch, m->get == NNGP_GET_NNGP ? m->kdiag : nullptr,
+                                m->get == NNGP_GET_NTK ? m->kdiag : nullptr, s));
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, m->kdiag, n, m->pcg.scal + 7);
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->pcg.host_scal + 7, m->pcg.scal + 7, sizeof(double), hipMemcpyDeviceToHost, s));
+    NNGP_HIP_CHECK(hipStreamSynchronize(s));
+    m->trace_mean = m->pcg.host_scal[7] / (double)n;
+    m->reg = m->absolute ? m->diag_reg : m->diag_reg * m->trace_mean;
+    m->have_train = true;
+    return 0;
+}
+
+int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->have_train, "build_rows: call set_train first");
+    NNGP_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= m->n, "build_rows: bad row range");
+    BuildArgs a{};
+    a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
+    a.n1 = m->n; a.n2 = m->n; a.d = m->d;
+    a.row_begin = row_begin; a.row_end = row_end;
+    a.sym = (row_begin == 0 && row_end == m->n) ? 1 : 0;
+    a.ld64 = a.ld32 = m->np;
+    if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
+    NNGP_TRY(launch_kernel_build(a, m->arch, s));
+    m->built = true;  // the caller vouches for the remaining rows (all-gather) before factor
+    m->factored = m->solved = false;
+    return 0;
+}
+
+int nngp_model_factor(nngp_model* m, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
+    NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, s));
+    NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
+    // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
+    NNGP_TRY(potrf_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), s));
+    m->factored = true;
+    m->solved = false;
+    return 0;
+}
+
+int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->factored, "solve: factor first");
+    if (max_iters <= 0) max_iters = 60;
+    if (tol <= 0.0) tol = 1e-12;
+    m->iters = 0;
+    m->relres = 0.0;
+    for (int c = 0; c < m->ny; ++c) {
+        NNGP_TRY(launch_strided_copy_f64(m->y + c, m->ny, m->pcg.bcol, 1, m->n, s));
+        int it = 0;
+        double rr = 0.0;
+        NNGP_TRY(pcg_solve(m->k64, m->np, m->n, m->reg, m->a32, m->np, m->dinv, m->np, m->pcg.bcol, m->pcg.xcol,
+                           m->pcg, max_iters, tol, &it, &rr, s));
+        NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
+        if (it > m->iters) m->iters = it;
+        if (rr > m->relres) m->relres = rr;
+    }
+    m->solved = true;
+    return 0;
+}
+
+int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, void* stream) {
+    NNGP_TRY(nngp_model_set_train(m, x, y, n, stream));
+    NNGP_TRY(nngp_model_build_rows(m, 0, n, stream));
+    NNGP_TRY(nngp_model_factor(m, stream));
+    return nngp_model_solve(m, 0, 0.0, stream);
+}
+
+int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld) {
+    NNGP_REQUIRE(m != nullptr && m->have_train, "kernel_buffer: call set_train first");
+    if (k64) *k64 = m->k64;
+    if (ld) *ld = m->np;
+    return 0;
+}
+
+int nngp_model_info(nngp_model* m, nngp_fit_info* info) {
+    NNGP_REQUIRE(m != nullptr && info != nullptr, "model_info: NULL argument");
+    int32_t cl = 0;
+    if (m->factored) NNGP_HIP_CHECK(hipMemcpy(&cl, m->clamped, sizeof(int32_t), hipMemcpyDeviceToHost));
+    info->reg = m->reg;
+    info->trace_mean = m->trace_mean;
+    info->rel_residual = m->relres;
+    info->refine_iters = m->iters;
+    info->clamped_pivots = cl;
+    info->n = m->n;
+    info->n_padded = m->np;
+    return 0;
+}
+
+int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream) {
+    NNGP_REQUIRE(m != nullptr && m->solved && alpha_out != nullptr, "model_alpha: solve first");
+    NNGP_HIP_CHECK(hipMemcpyAsync(alpha_out, m->alpha, sizeof(double) * m->n * m->ny, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return 0;
+}
+
+int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode, double* mean,
+                       double* var_or_cov, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->solved, "predict: fit the model first");
+    NNGP_REQUIRE(cov_mode >= NNGP_COV_NONE && cov_mode <= NNGP_COV_FULL, "predict: bad cov_mode");
+    NNGP_REQUIRE(mean != nullptr && (cov_mode == NNGP_COV_NONE || var_or_cov != nullptr), "predict: NULL output");
+    NNGP_REQUIRE(cov_mode == NNGP_COV_NONE || m->get == NNGP_GET_NNGP,
+                 "predict: the NTK posterior covariance is not implemented yet (mean only)");
+    const bool on_train = (x_test == nullptr);
+    if (on_train) mt = m->n;
+    NNGP_REQUIRE(mt >= 0, "predict: negative row count");
+    if (mt == 0) return 0;
+    const int64_t n = m->n, np = m->np, mp = round_up(mt, TB);
+    NNGP_TRY(ensure_predict_capacity(m, mt, !on_train));
+
+    const double* xt = on_train ? m->x : x_test;
+    const double* ktd = m->k64;  // x_test=None: K_td = K_dd (estimator.py:37-40)
+    const double* qt = m->q;
+    if (!on_train) {
+        NNGP_TRY(launch_row_sqnorm(xt, mt, m->d, m->xt_q, s));
+        qt = m->xt_q;
+        BuildArgs a{};
+        a.x1 = xt; a.x2 = m->x; a.q1 = m->xt_q; a.q2 = m->q;
+        a.n1 = mt; a.n2 = n; a.d = m->d;
+        a.row_begin = 0; a.row_end = mt; a.sym = 0;
+        a.ld64 = a.ld32 = np;
+        if (m->get == NNGP_GET_NNGP) a.nngp64 = m->ktd64; else a.ntk64 = m->ktd64;
+        NNGP_TRY(launch_kernel_build(a, m->arch, s));
+        ktd = m->ktd64;
+    }
+    for (int c = 0; c < m->ny; ++c)
+        NNGP_TRY(launch_gemv_f64(ktd, np, mt, n, m->alpha + c, m->ny, mean + c, m->ny, 0.0, s));
+    if (cov_mode == NNGP_COV_NONE) return 0;
+
+    // V^T = K_td L^-T  (float32 MFMA triangular solve with mt right-hand sides)
+    NNGP_TRY(launch_convert_f64_f32(ktd, np, m->b32, np, mt, n, mp, np, s));
+    NNGP_TRY(trsm_rlt_f32(m->b32, np, mp, m->a32, np, m->dinv, np, s));
+    if (cov_mode == NNGP_COV_DIAG) {
+        NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));
+        return launch_row_sqsum_f32(m->b32, np, mt, np, m->tt_diag, var_or_cov, s);
+    }
+    // full covariance: K_tt - V^T V
+    NNGP_TRY(ensure_full_cov_capacity(m, mt));
+    {
+        BuildArgs a{};
+        a.x1 = xt; a.x2 = xt; a.q1 = qt; a.q2 = qt;
+        a.n1 = mt; a.n2 = mt; a.d = m->d;
+        a.row_begin = 0; a.row_end = mt; a.sym = 1;
+        a.ld64 = a.ld32 = mp;
+        a.nngp64 = m->ktt64;
+        NNGP_TRY(launch_kernel_build(a, m->arch, s));
+    }
+    NNGP_TRY(launch_gemm_nt_f32(m->vvt32, mp, m->b32, np, m->b32, np, mp, mp, np, 1.0f, 0.0f, false, s));
+    return launch_cov_finish(m->ktt64, mp, m->vvt32, mp, mt, var_or_cov, s);
+}
+
+int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream) {
+    NNGP_REQUIRE(a != nullptr && dinv != nullptr, "potrf_f32: NULL argument");
+    if (clamped) NNGP_HIP_CHECK(hipMemsetAsync(clamped, 0, sizeof(int32_t), (hipStream_t)stream));
+    return potrf_f32(a, n, ld, dinv, clamped, 0.0f, (hipStream_t)stream);
+}
+
+int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
+                     int64_t n, int64_t k, float alpha, float beta, int32_t lower_only, void* stream) {
+    NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr, "gemm_nt_f32: NULL argument");
+    return launch_gemm_nt_f32(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only != 0, (hipStream_t)stream);
+}
+
+int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
+                      void* stream) {
+    NNGP_REQUIRE(b != nullptr && l != nullptr && dinv != nullptr, "trsm_rlt_f32: NULL argument");
+    NNGP_REQUIRE(m % TB == 0 && n % TB == 0 && m > 0 && n > 0, "trsm_rlt_f32: m, n must be multiples of %d", TB);
+    return trsm_rlt_f32(b, ldb, m, l, ldl, dinv, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

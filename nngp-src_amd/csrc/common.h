@@ -1,0 +1,110 @@
+// Internal helpers shared by the HIP translation units of libnngp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nngp_hip.h"
+
+namespace nngp {
+
+constexpr int TB = 128;  // Cholesky / GEMM tile edge; all float32 device matrices are padded to it
+
+void set_error(const char* fmt, ...);
+
+#define NNGP_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            nngp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -1;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+#define NNGP_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            nngp::set_error(__VA_ARGS__);  \
+            return -2;                     \
+        }                                  \
+    } while (0)
+
+#define NNGP_TRY(expr)          \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// Squared layer parameters in kernel-argument form.
+struct ArchDev {
+    int n_dense;
+    double w2[NNGP_MAX_DENSE];
+    double b2[NNGP_MAX_DENSE];
+};
+
+int make_arch_dev(const nngp_arch* arch, ArchDev* out);
+
+// ---- kernel_build.hip ----
+struct BuildArgs {
+    const double* x1;
+    const double* x2;   // == x1 when symmetric
+    const double* q1;   // |x1_i|^2 / d
+    const double* q2;
+    int64_t n1, n2;
+    int d;
+    int64_t row_begin, row_end;
+    int sym;            // 1: x2 == x1, only tiles with col-tile <= row-tile are computed, then mirrored
+    double* nngp64;     // any of the four outputs may be NULL
+    double* ntk64;
+    float* nngp32;
+    float* ntk32;
+    int64_t ld64, ld32;
+    double diag_add_nngp32;  // added on the diagonal of the float32 outputs (regulariser), sym only
+    double diag_add_ntk32;
+    int lower32;        // 1: float32 outputs only get the lower triangle (factorisation input)
+};
+int launch_row_sqnorm(const double* x, int64_t n, int d, double* q, hipStream_t s);
+int launch_diag_from_q(const double* q, int64_t n, const ArchDev& arch, double* dn, double* dt, hipStream_t s);
+int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s);
+
+// ---- gemm_f32.hip ----
+int launch_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s);
+
+// ---- potrf.hip ----
+int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
+int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s);
+int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
+                 hipStream_t s);
+
+// ---- solve.hip ----
+// z = L^-1 r (forward) then w = L^-T z (backward), float32 factor with inverted 128-blocks.
+int trsv_forward_f32(const float* l, int64_t ld, const float* dinv, int64_t n, float* b, float* x, hipStream_t s);
+int trsv_backward_f32(const float* l, int64_t ld, const float* dinv, int64_t n, float* b, float* x, hipStream_t s);
+int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, const double* x, int64_t incx,
+                    double* y, int64_t incy, double diag_add, hipStream_t s);
+struct PcgWork {
+    double* r; double* z; double* p; double* q; double* xcol; double* bcol;
+    float* f32a; float* f32b; float* f32c;
+    double* scal;       // device scalars [8]
+    double* host_scal;  // pinned host [8]
+};
+int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
+              const float* dinv, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
+              double tol, int* iters_out, double* relres_out, hipStream_t s);
+
+// ---- posterior.hip ----
+int launch_convert_f64_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
+                           int64_t rows_p, int64_t cols_p, hipStream_t s);
+int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np,
+                        double reg, hipStream_t s);
+int launch_row_sqsum_f32(const float* v, int64_t ld, int64_t rows, int64_t cols, const double* base,
+                         double* out, hipStream_t s);
+int launch_cov_finish(const double* ktt, int64_t ldk, const float* vvt, int64_t ldv, int64_t m, double* cov,
+                      hipStream_t s);
+int launch_strided_copy_f64(const double* src, int64_t incs, double* dst, int64_t incd, int64_t n, hipStream_t s);
+
+}  // namespace nngp

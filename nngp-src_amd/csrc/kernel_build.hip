@@ -1,0 +1,265 @@
+// K1: fused NNGP/NTK kernel build for gfx950.
+//
+// Replaces kernel_fn of stax.serial(Dense, Relu, Dense) (reference train.py:161-164,
+// estimator.py:27-30; closed forms in SURVEY.md 8a row a1).  One 64x64 output tile per
+// 256-thread workgroup: the x1 / x2 row panels are staged through LDS, the Gram entries
+// x.x'/d are accumulated in float64 registers (4x4 per thread) and the whole layer recursion
+// (Dense affine, ReLU arc-cosine map with sqrt + atan2, NTK chain) runs in the epilogue on the
+// accumulators, so K (and Theta) are written to HBM exactly once.  In symmetric mode only tiles on
+// or below the diagonal are computed; the mirror image is transposed through LDS and written with
+// the same coalesced 16-byte stores.
+//
+// Everything is float64: the GP solve behind this kernel has cond ~ 1e7, and a float32 Gram
+// perturbs posterior means by ~2.5e-4, over the 1e-4 parity gate.
+#include "common.h"
+
+namespace nngp {
+
+namespace {
+
+constexpr int KT = 64;       // output tile edge
+constexpr int KC = 16;       // k-chunk staged per iteration
+constexpr int LDP = KT + 2;  // LDS row stride in doubles (keeps 16-byte alignment of every row)
+constexpr double kPi = 3.14159265358979323846;
+
+__global__ __launch_bounds__(256) void k_row_sqnorm(const double* __restrict__ x, int64_t n, int d,
+                                                    double* __restrict__ q) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    const double* xr = x + row * (int64_t)d;
+    double s = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = xr[k];
+        s = fma(v, v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) q[row] = s / (double)d;
+}
+
+__global__ __launch_bounds__(256) void k_diag_from_q(const double* __restrict__ q, int64_t n, ArchDev arch,
+                                                     double* __restrict__ dn, double* __restrict__ dt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double k = q[i], t = 0.0;
+    for (int l = 0; l < arch.n_dense; ++l) {
+        k = fma(arch.w2[l], k, arch.b2[l]);
+        t = fma(arch.w2[l], t, k);
+        if (l < arch.n_dense - 1) {
+            k *= 0.5;  // s = 0, theta = 0 on the diagonal
+            t *= 0.5;
+        }
+    }
+    if (dn) dn[i] = k;
+    if (dt) dt[i] = t;
+}
+
+// One matrix element through Dense,(Relu,Dense)*.  exact_diag: element (i, i) of a symmetric build,
+// where q q' - k^2 == 0 exactly (k is replaced by q so rounding of the dot product cannot leak in).
+__device__ __forceinline__ void layer_map(double k, double q1, double q2, const ArchDev& arch, bool exact_diag,
+                                          double& out_k, double& out_t) {
+    double t = 0.0;
+    if (exact_diag) k = q1;
+    for (int l = 0; l < arch.n_dense; ++l) {
+        const double w2 = arch.w2[l], b2 = arch.b2[l];
+        k = fma(w2, k, b2);
+        q1 = fma(w2, q1, b2);
+        q2 = fma(w2, q2, b2);
+        t = fma(w2, t, k);
+        if (l < arch.n_dense - 1) {
+            if (exact_diag) {
+                k *= 0.5;
+                t *= 0.5;
+            } else {
+                const double r = fma(q1, q2, -k * k);
+                const double s = r > 0.0 ? sqrt(r) : 0.0;
+                const double th = (s == 0.0 && k == 0.0) ? 0.5 * kPi : atan2(s, k);
+                const double kd = (kPi - th) * (0.5 / kPi);
+                k = fma(kd, k, s * (0.5 / kPi));
+                t *= kd;
+            }
+            q1 *= 0.5;
+            q2 *= 0.5;
+        }
+    }
+    out_k = k;
+    out_t = t;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* base, int64_t ld, int64_t i, int64_t j, int64_t i_end, int64_t j_end,
+                                       const double v[4], bool vec_ok) {
+    if (base == nullptr || i >= i_end) return;
+    T* p = base + i * ld + j;
+    if (vec_ok && j + 3 < j_end) {
+        if constexpr (sizeof(T) == 8) {
+            reinterpret_cast<double2*>(p)[0] = make_double2(v[0], v[1]);
+            reinterpret_cast<double2*>(p)[1] = make_double2(v[2], v[3]);
+        } else {
+            reinterpret_cast<float4*>(p)[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (j + c < j_end) p[c] = (T)v[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_build(BuildArgs a, ArchDev arch, int64_t tiles_c, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) double smem[KT * LDP];  // As | Bs during the k-loop, T for the mirror
+    double* As = smem;             // [KC][LDP]
+    double* Bs = smem + KC * LDP;  // [KC][LDP]
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+
+    int64_t bi, bj;
+    if (a.sym) {
+        const int64_t p = blockIdx.x;
+        bi = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+        while (bi * (bi + 1) / 2 > p) --bi;
+        while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
+        bj = p - bi * (bi + 1) / 2;
+    } else {
+        bi = blockIdx.x / tiles_c;
+        bj = blockIdx.x % tiles_c;
+    }
+    const int64_t i0 = a.row_begin + bi * KT, j0 = bj * KT;
+    const int64_t i_end = a.row_end, j_end = a.n2;
+
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+
+    for (int k0 = 0; k0 < a.d; k0 += KC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;
+            const int kk = idx & (KC - 1), row = idx >> 4;
+            const int kg = k0 + kk;
+            const int64_t gi = i0 + row, gj = j0 + row;
+            As[kk * LDP + row] = (kg < a.d && gi < i_end) ? a.x1[gi * a.d + kg] : 0.0;
+            Bs[kk * LDP + row] = (kg < a.d && gj < j_end) ? a.x2[gj * a.d + kg] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] = As[kk * LDP + ty + 16 * r];
+            const double2 b01 = *reinterpret_cast<const double2*>(&Bs[kk * LDP + tx * 4]);
+            const double2 b23 = *reinterpret_cast<const double2*>(&Bs[kk * LDP + tx * 4 + 2]);
+            bv[0] = b01.x; bv[1] = b01.y; bv[2] = b23.x; bv[3] = b23.y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: layer recursion on the accumulators ----
+    const double inv_d = 1.0 / (double)a.d;
+    double q2v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t gj = j0 + tx * 4 + c;
+        q2v[c] = gj < j_end ? a.q2[gj] : 0.0;
+    }
+    double kn[4][4], kt[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t gi = i0 + ty + 16 * r;
+        const double q1v = gi < i_end ? a.q1[gi] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t gj = j0 + tx * 4 + c;
+            layer_map(acc[r][c] * inv_d, q1v, q2v[c], arch, a.sym && gi == gj, kn[r][c], kt[r][c]);
+        }
+    }
+    const bool vec = vec_ok != 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t gi = i0 + ty + 16 * r, gj = j0 + tx * 4;
+        store4(a.nngp64, a.ld64, gi, gj, i_end, j_end, kn[r], vec);
+        store4(a.ntk64, a.ld64, gi, gj, i_end, j_end, kt[r], vec);
+        store4(a.nngp32, a.ld32, gi, gj, i_end, j_end, kn[r], vec);
+        store4(a.ntk32, a.ld32, gi, gj, i_end, j_end, kt[r], vec);
+    }
+
+    // ---- mirror image of an off-diagonal tile (symmetric build): transpose through LDS ----
+    if (a.sym && bi != bj) {
+        for (int which = 0; which < 2; ++which) {
+            if (which == 0 && a.nngp64 == nullptr && a.nngp32 == nullptr) continue;
+            if (which == 1 && a.ntk64 == nullptr && a.ntk32 == nullptr) continue;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    smem[(tx * 4 + c) * LDP + ty + 16 * r] = which == 0 ? kn[r][c] : kt[r][c];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v[4];
+                const double2 v01 = *reinterpret_cast<const double2*>(&smem[(ty + 16 * r) * LDP + tx * 4]);
+                const double2 v23 = *reinterpret_cast<const double2*>(&smem[(ty + 16 * r) * LDP + tx * 4 + 2]);
+                v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+                // element (j0 + ty + 16 r, i0 + tx*4 + c); rows bounded by n2 (= n1), columns by row_end
+                const int64_t mi = j0 + ty + 16 * r, mj = i0 + tx * 4;
+                if (which == 0) {
+                    store4(a.nngp64, a.ld64, mi, mj, j_end, i_end, v, vec);
+                    store4(a.nngp32, a.ld32, mi, mj, j_end, i_end, v, vec);
+                } else {
+                    store4(a.ntk64, a.ld64, mi, mj, j_end, i_end, v, vec);
+                    store4(a.ntk32, a.ld32, mi, mj, j_end, i_end, v, vec);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_row_sqnorm(const double* x, int64_t n, int d, double* q, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, q);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_diag_from_q(const double* q, int64_t n, const ArchDev& arch, double* dn, double* dt, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_diag_from_q, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, n, arch, dn, dt);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) {
+    const int64_t rows = a.row_end - a.row_begin;
+    if (rows <= 0 || a.n2 <= 0) return 0;
+    NNGP_REQUIRE(a.d > 0, "kernel_build: d must be positive");
+    const int64_t tiles_r = (rows + KT - 1) / KT, tiles_c = (a.n2 + KT - 1) / KT;
+    int64_t nblocks;
+    if (a.sym) {
+        NNGP_REQUIRE(a.row_begin == 0 && a.row_end == a.n1 && a.n1 == a.n2,
+                     "kernel_build: symmetric mode needs the full row range");
+        nblocks = tiles_r * (tiles_r + 1) / 2;
+    } else {
+        nblocks = tiles_r * tiles_c;
+    }
+    NNGP_REQUIRE(nblocks < (int64_t)2147483647, "kernel_build: grid too large (%lld tiles)", (long long)nblocks);
+    // 16-byte stores are legal when every row start is 16-byte aligned for every output in use
+    auto aligned = [](const void* p, int64_t ld, int esz) {
+        return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ((ld * esz) & 15) == 0);
+    };
+    int vec_ok = aligned(a.nngp64, a.ld64, 8) && aligned(a.ntk64, a.ld64, 8) && aligned(a.nngp32, a.ld32, 4) &&
+                 aligned(a.ntk32, a.ld32, 4) && (a.row_begin % 4 == 0);
+    hipLaunchKernelGGL(k_build, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace nngp

@@ -1,0 +1,121 @@
+"""Row-block data parallelism for the kernel build (the ``nt.batch(device_count=...)`` slot).
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU
+tests).  Row i of K depends only on x_i and X, so rank g builds the contiguous block
+``[g*chunk, (g+1)*chunk)`` and ONE all-gather gives every rank the full float64 kernel for the replicated
+Cholesky.  No other collective touches the data path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world_size() -> int:
+    dist = _dist()
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    dist = _dist()
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def row_chunk(n: int, world: int) -> int:
+    return (n + world - 1) // world
+
+
+def row_partition(n: int, world: int, r: int):
+    """Rows [r0, r1) owned by rank r: equal chunks of ceil(n/world), the tail ranks may be short or empty."""
+    c = row_chunk(n, world)
+    return min(r * c, n), min((r + 1) * c, n)
+
+
+def allgather_rows(buf, n: int, group=None):
+    """All-gather the row blocks of ``buf`` ([rows >= world*chunk, ld] torch tensor) in place.
+
+    Every rank must have written its own rows ``row_partition(n, world, rank)``; on return rows [0, n) are
+    complete on every rank.  Sends exactly chunk*ld elements per rank (the short tail block is padded by
+    whatever the buffer holds -- rows >= n are never read).
+    """
+    import torch
+    dist = _dist()
+    world, r = world_size(), rank()
+    if world == 1:
+        return buf
+    c = row_chunk(n, world)
+    if buf.shape[0] < world * c:
+        raise ValueError("all-gather buffer has %d rows, needs %d" % (buf.shape[0], world * c))
+    mine = buf[r * c:(r + 1) * c].contiguous().clone()
+    out = buf[: world * c]
+    if out.is_contiguous():
+        dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
+    else:  # pragma: no cover
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        for g, p in enumerate(parts):
+            out[g * c:(g + 1) * c].copy_(p)
+    return buf
+
+
+def sharded_kernel(kernel_fn, x1, x2=None, get="nngp", group=None):
+    """kernel_fn over row blocks of x1 on every rank + one all-gather; returns the full [N1, N2] array."""
+    import torch
+    world, r = world_size(), rank()
+    n1 = int(np.shape(x1)[0])
+    n2 = n1 if x2 is None else int(np.shape(x2)[0])
+    if world == 1:
+        return kernel_fn(x1, x2, get)
+    if not isinstance(get, str):
+        raise NotImplementedError("sharded_kernel: one kernel per call")
+    c = row_chunk(n1, world)
+    r0, r1 = row_partition(n1, world, r)
+    backend = _dist().get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.zeros((world * c, n2), dtype=torch.float64, device=dev)
+    if r1 > r0:
+        blk = kernel_fn(x1, x2, get, rows=(r0, r1))
+        buf[r0:r1] = torch.as_tensor(np.asarray(blk), dtype=torch.float64).to(dev) if not isinstance(blk, torch.Tensor) else blk
+    allgather_rows(buf, n1, group)
+    return buf[:n1].cpu().numpy()
+
+
+def sharded_fit(model, x, y, group=None, timings=None):
+    """GPModel fit with the kernel build sharded over ranks: build own rows -> all-gather -> replicated
+    factor + solve.  The model must have been created with n_cap >= world * ceil(n / world)."""
+    import torch
+    world, r = world_size(), rank()
+    model.set_train(x, y)
+    n = model.n
+    r0, r1 = row_partition(n, world, r)
+    ev = lambda: _event()
+    t0 = ev()
+    if world == 1:
+        model.build_rows(0, n)
+    else:
+        model.build_rows(r0, r1)
+    t1 = ev()
+    if world > 1:
+        buf, _ = model.kernel_buffer(all_rows=True)
+        allgather_rows(buf, n, group)
+    t2 = ev()
+    model.factor()
+    t3 = ev()
+    model.solve()
+    t4 = ev()
+    if timings is not None:
+        torch.cuda.synchronize()
+        timings.update(build_ms=t0.elapsed_time(t1), allgather_ms=t1.elapsed_time(t2), factor_ms=t2.elapsed_time(t3),
+                       solve_ms=t3.elapsed_time(t4))
+    return model
+
+
+def _event():
+    import torch
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    return e

@@ -1,0 +1,135 @@
+"""GPModel: Python owner of one ``nngp_model`` handle (C ABI, include/nngp_hip.h).
+
+One object = one exact GP posterior for one ``get`` ('nngp' or 'ntk'): the float64 train-train kernel,
+its float32 MFMA Cholesky factor and alpha = (K + reg I)^-1 Y, all resident in HBM.  This is what the
+closure returned by ``nt.predict.gradient_descent_mse_ensemble`` caches in the reference
+(train.py:171-172).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_GET = {"nngp": _lib.GET_NNGP, "ntk": _lib.GET_NTK}
+_COV = {False: _lib.COV_NONE, None: _lib.COV_NONE, "none": _lib.COV_NONE, "diag": _lib.COV_DIAG,
+        True: _lib.COV_FULL, "full": _lib.COV_FULL}
+
+
+class GPModel:
+    def __init__(self, n_cap: int, d: int, w_std, b_std, get: str = "nngp", diag_reg: float = 1e-3,
+                 diag_reg_absolute_scale: bool = False, ny: int = 1, m_cap: int = 0):
+        if get not in _GET:
+            raise ValueError("get must be 'nngp' or 'ntk', got %r" % (get,))
+        self.lib = _lib.load()
+        self.device = _lib.require_gpu()
+        self.get, self.d, self.ny, self.n_cap = get, int(d), int(ny), int(n_cap)
+        self.arch = _lib.make_arch(w_std, b_std)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.nngp_model_create(ctypes.byref(self.handle), int(n_cap), int(m_cap), int(d), int(ny),
+                                              ctypes.byref(self.arch), _GET[get], float(diag_reg),
+                                              int(bool(diag_reg_absolute_scale))))
+        self.n = 0
+        self._keep = []  # device tensors that must outlive asynchronous work
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.nngp_model_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stages (bench.py times them separately; the multi-GPU path shards build_rows) ----
+    def set_train(self, x, y):
+        xd = _lib.to_device_f64(x, self.device)
+        yd = _lib.to_device_f64(y, self.device).reshape(xd.shape[0], -1)
+        if xd.ndim != 2 or xd.shape[1] != self.d:
+            raise ValueError("x_train must be [N, %d], got %s" % (self.d, tuple(xd.shape)))
+        if yd.shape[1] != self.ny:
+            raise ValueError("y_train must have %d column(s), got %s" % (self.ny, tuple(yd.shape)))
+        self.n = int(xd.shape[0])
+        self._keep = [xd, yd]
+        _lib.check(self.lib.nngp_model_set_train(self.handle, _lib.ptr(xd), _lib.ptr(yd), self.n, _lib.stream_ptr()))
+
+    def build_rows(self, row_begin: int = 0, row_end: int = None):
+        row_end = self.n if row_end is None else row_end
+        _lib.check(self.lib.nngp_model_build_rows(self.handle, int(row_begin), int(row_end), _lib.stream_ptr()))
+
+    def factor(self):
+        _lib.check(self.lib.nngp_model_factor(self.handle, _lib.stream_ptr()))
+
+    def solve(self, max_iters: int = 0, tol: float = 0.0):
+        _lib.check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
+
+    def fit(self, x, y):
+        self.set_train(x, y)
+        self.build_rows(0, self.n)
+        self.factor()
+        self.solve()
+        return self
+
+    def kernel_buffer(self, all_rows: bool = False):
+        """(torch view of the float64 train-train kernel in HBM, ld).  The view is [n, ld], or every row the
+        allocation can hold at this ld when ``all_rows`` (the RCCL all-gather writes whole chunks)."""
+        p, ld = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(self.lib.nngp_model_kernel_buffer(self.handle, ctypes.byref(p), ctypes.byref(ld)))
+        np_cap = (self.n_cap + 127) // 128 * 128
+        rows = (np_cap * np_cap) // ld.value if all_rows else self.n
+        return _wrap_device_f64(p.value, rows * ld.value, self.device).view(rows, ld.value), ld.value
+
+    def info(self) -> dict:
+        fi = _lib.NngpFitInfo()
+        _lib.check(self.lib.nngp_model_info(self.handle, ctypes.byref(fi)))
+        return {k: getattr(fi, k) for k, _ in fi._fields_}
+
+    def alpha(self):
+        import torch
+        out = torch.empty((self.n, self.ny), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.nngp_model_alpha(self.handle, _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
+    # ---- predict_fn(x_test, get, compute_cov) ----
+    def predict(self, x_test=None, cov="diag", as_numpy=True):
+        """mean [M, ny] (+ var [M] for cov='diag', cov [M, M] for cov='full'/True)."""
+        import torch
+        mode = _COV[cov]
+        if x_test is None:
+            xt, m = None, self.n
+        else:
+            xt = _lib.to_device_f64(x_test, self.device)
+            if xt.ndim != 2 or xt.shape[1] != self.d:
+                raise ValueError("x_test must be [M, %d], got %s" % (self.d, tuple(xt.shape)))
+            m = int(xt.shape[0])
+        mean = torch.empty((m, self.ny), dtype=torch.float64, device=self.device)
+        out = None
+        if mode == _lib.COV_DIAG:
+            out = torch.empty((m,), dtype=torch.float64, device=self.device)
+        elif mode == _lib.COV_FULL:
+            out = torch.empty((m, m), dtype=torch.float64, device=self.device)
+        if m > 0:
+            _lib.check(self.lib.nngp_model_predict(self.handle, _lib.ptr(xt), m, mode, _lib.ptr(mean), _lib.ptr(out),
+                                                   _lib.stream_ptr()))
+        if as_numpy:
+            mean = mean.cpu().numpy()
+            out = None if out is None else out.cpu().numpy()
+        return mean if out is None else (mean, out)
+
+
+def _wrap_device_f64(address: int, count: int, device):
+    """Zero-copy torch view of library-owned HBM (float64)."""
+    import torch
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (address, False), "version": 3,
+                                  "strides": None}
+    return torch.as_tensor(h, device=device)

@@ -1,0 +1,113 @@
+"""The reference-shaped Python surface on the GPU (-m gpu): stax / batch / predict / Estimator / train CLI."""
+import contextlib
+import io
+import os
+import types
+
+import numpy as np
+import pytest
+
+import nngp_oracle as o
+import nngp_src_amd as nt
+from nngp_src_amd import encoder as enc, stax, synth, train as train_cli
+from nngp_src_amd.estimator import Estimator
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_call_sequence():
+    """The exact call sequence of train.py:161-172,157-158 with the reference's hyper-parameters."""
+    x, y = synth.synthetic_queries(400, 20, seed=0)
+    xt, _ = synth.synthetic_queries(33, 20, seed=1)
+    init_fn, apply_fn, kernel_fn = stax.serial(stax.Dense(512), stax.Relu(), stax.Dense(1))
+    kernel_fn = nt.batch(kernel_fn, device_count=0, batch_size=0)
+    predict_fn = nt.predict.gradient_descent_mse_ensemble(kernel_fn, x, y, diag_reg=1e-3)
+    pred_mean, pred_cov = predict_fn(x_test=xt, get="nngp", compute_cov=True)
+    assert pred_mean.shape == (33, 1) and pred_cov.shape == (33, 33)
+    post = o.Posterior(x, y, o.make_arch(1), diag_reg=1e-3)
+    m_ref, c_ref = post.predict(xt, "nngp", True)
+    assert G.mean_gate(pred_mean, m_ref)[0] < 1e-6
+    np.testing.assert_allclose(np.sqrt(np.diag(pred_cov)), np.sqrt(np.diag(c_ref)), rtol=1e-3)
+    # mean only / ntk / tuple get / kernel_fn forms
+    assert np.array_equal(predict_fn(x_test=xt, get="nngp", compute_cov=False), pred_mean)
+    both = predict_fn(x_test=xt, get=("nngp", "ntk"))
+    assert G.mean_gate(both.ntk, post.predict(xt, "ntk", False))[0] < 1e-6
+    k = kernel_fn(xt, x, "nngp")
+    np.testing.assert_allclose(k, o.kernel_fn(xt, x, "nngp", o.make_arch(1)), rtol=1e-11)
+    kk = kernel_fn(xt, None, ("nngp", "ntk"))
+    np.testing.assert_allclose(kk.ntk, o.kernel_fn(xt, None, "ntk", o.make_arch(1)), rtol=1e-7)
+    assert kernel_fn(xt).nngp.shape == (33, 33)
+    with pytest.raises(NotImplementedError):
+        predict_fn(t=1.0, x_test=xt, get="nngp")
+    with pytest.raises(ValueError):
+        kernel_fn(xt, x[:, :5], "nngp")
+
+
+def test_batch_tiles_serially():
+    x, _ = synth.synthetic_queries(256, 64, seed=2)
+    _, _, kernel_fn = stax.serial(stax.Dense(512), stax.Relu(), stax.Dense(512), stax.Relu(), stax.Dense(1))
+    full = kernel_fn(x, None, "nngp")
+    tiled = nt.batch(kernel_fn, batch_size=64, device_count=0)(x, None, "nngp")
+    np.testing.assert_allclose(tiled, full, rtol=1e-13)
+
+
+def _toy_encoder():
+    tables = [enc.TableEncoder("a", [enc.numerical("k", 0, 10), enc.numerical("v", 0, 100), enc.numerical("w", -5, 5)], 64),
+              enc.TableEncoder("b", [enc.numerical("k", 0, 10), enc.categorical("c", 70)], 64)]
+    return enc.NNGPEncoder(tables)
+
+
+def test_estimator_serving_path(tmp_path):
+    rng = np.random.default_rng(0)
+    lines = []
+    for i in range(300):
+        up, lo = sorted(rng.uniform(0, 100, 2), reverse=True)
+        wu, wl = sorted(rng.uniform(-5, 5, 2), reverse=True)
+        card = max(1, int(5000 * (up - lo) / 100 * (wu - wl) / 10))
+        if i % 3 == 0:
+            lines.append("a,b@v,%.2f,%.2f#w,%.2f,%.2f@c,%d,%d@a,b,k@%d" % (up, lo, wu, wl, i % 70, (i * 7) % 70, card * 3))
+        else:
+            lines.append("a@v,%.2f,%.2f#w,%.2f,%.2f@@%d" % (up, lo, wu, wl, card))
+    (tmp_path / "q.txt").write_text("\n".join(lines) + "\n")
+    je = _toy_encoder()
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        est = Estimator("toy", "", str(tmp_path), encoder=je)
+        est.load_model()
+        serve = [l.rsplit("@", 1)[0] for l in lines[:40]]
+        pred_mean, pred_std = est.predict(serve)
+    assert "Model construction complete." in buf.getvalue() and "prediction time=" in buf.getvalue()
+    assert pred_mean.shape == (40,) and pred_std.shape == (40,)
+    post = o.Posterior(est.X_train, est.Y_train, o.make_arch(1), diag_reg=1e-3)
+    xt = np.array([je.parse_line_without_card_then_encode(l) for l in serve])
+    m_ref, c_ref = post.predict(xt, "nngp", True)
+    assert G.mean_gate(pred_mean, m_ref)[0] < 1e-6
+    np.testing.assert_allclose(pred_std, np.sqrt(np.diag(c_ref)), rtol=2e-3)
+
+
+def test_train_cli_on_forest_queries(golden_dir, tmp_path):
+    """train.py --kernel_type nngp on the reference's forest queries (config 1: 1000 train / 200 test)."""
+    g = np.load(os.path.join(golden_dir, "forest_queries.npz"))
+    sent = np.iinfo(np.int32).min
+    names = "ABCDEFGHIJ"
+    per_file = 2000
+    for fi, fn in enumerate(g["files"]):
+        with open(tmp_path / str(fn), "w") as f:
+            for i in range(fi * per_file, (fi + 1) * per_file):
+                preds = ["%s,%d,%d" % (names[c], g["bounds"][i, c, 0], g["bounds"][i, c, 1]) for c in range(10)
+                         if g["bounds"][i, c, 0] != sent]
+                f.write("#".join(preds) + "@%d\n" % g["cards"][i])
+    args = train_cli.make_parser().parse_args(["--kernel_type", "nngp", "--query_path", str(tmp_path),
+                                               "--max_num_train", "1000", "--max_num_test", "200"])
+    args.join_query = False
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = train_cli.main(args)
+    text = buf.getvalue()
+    for needle in ("number of query: 18000", "(1000, 20) (200, 20)", "Kernel construction in", "Mean Square Error:",
+                   "Inference time=", "Predict Result Profile of 200 Queries:", "Query attributes:num_table=1"):
+        assert needle in text, needle
+    gold = np.load(os.path.join(golden_dir, "forest_n1000_m200.npz"))
+    assert G.mean_gate(res["pred_mean"], gold["nngp_mean"])[0] < 1e-6
+    np.testing.assert_allclose(res["pred_std"], np.sqrt(gold["nngp_var"]), rtol=1e-3)

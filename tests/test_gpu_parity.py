@@ -1,0 +1,289 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the float64 oracle.
+
+Tolerances: kernel build is float64 arithmetic -> 1e-11 relative; posterior means must meet the
+north-star gate of 1e-4 relative (we assert 1e-6: CG on the float64 kernel converges to the float64
+answer); variances 1e-3 relative (float32 triangular solve); float32 MFMA GEMM is checked bit-exactly
+on integer data and to float32 rounding on random data.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+import c_oracle
+import nngp_oracle as o
+from nngp_src_amd import synth
+from nngp_src_amd.model import GPModel
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------- kernel build (a1)
+@pytest.mark.parametrize("n,d,n_relu,w,b", [(1, 1, 1, 1.0, 0.0), (63, 20, 1, 1.0, 0.0), (65, 3, 1, 1.0, 0.0),
+                                            (130, 79, 3, 1.0, 0.0), (257, 64, 2, 1.4, 0.25), (200, 256, 1, 1.0, 0.0)])
+def test_kernel_build_symmetric(n, d, n_relu, w, b):
+    rng = np.random.default_rng(n * 7 + d)
+    x = rng.uniform(0, 1000, size=(n, d))
+    a = o.make_arch(n_relu, w, b)
+    out = G.kernel_build(x, None, a.w_std, a.b_std)
+    K, T = o.kernel_fn(x, None, ("nngp", "ntk"), a)
+    assert not np.isnan(out["nngp"]).any() and not np.isnan(out["ntk"]).any()
+    np.testing.assert_allclose(out["nngp"], K, rtol=1e-11, atol=1e-12 * np.abs(K).max())
+    # off-diagonal NTK to 1e-9; the diagonal of the oracle carries sqrt(rounding) noise (theta ~ 1e-8), ours is exact
+    np.testing.assert_allclose(out["ntk"], T, rtol=1e-7, atol=1e-9 * np.abs(T).max())
+    assert np.array_equal(out["nngp"], out["nngp"].T) and np.array_equal(out["ntk"], out["ntk"].T)
+    q = np.sum(x * x, axis=1) / d
+    kd, td = o.diag_kernel(q, a)
+    np.testing.assert_allclose(np.diag(out["nngp"]), kd, rtol=1e-13)
+    np.testing.assert_allclose(np.diag(out["ntk"]), td, rtol=1e-13)
+
+
+@pytest.mark.parametrize("n1,n2,d", [(5, 300, 20), (129, 64, 7), (64, 129, 128), (300, 1, 20)])
+def test_kernel_build_rectangular_and_padded_ld(n1, n2, d):
+    rng = np.random.default_rng(n1 + n2)
+    x1, x2 = rng.uniform(0, 1000, size=(n1, d)), rng.uniform(0, 1000, size=(n2, d))
+    a = o.make_arch(1)
+    out = G.kernel_build(x1, x2, a.w_std, a.b_std, ld=n2 + 3)
+    K, T = o.kernel_fn(x1, x2, ("nngp", "ntk"), a)
+    np.testing.assert_allclose(out["nngp"][:, :n2], K, rtol=1e-11, atol=1e-12 * np.abs(K).max())
+    np.testing.assert_allclose(out["ntk"][:, :n2], T, rtol=1e-9, atol=1e-12 * np.abs(T).max())
+    assert np.isnan(out["nngp"][:, n2:]).all()  # padding columns untouched
+
+
+def test_kernel_build_row_shard_equals_full():
+    x, _ = synth.synthetic_queries(333, 64, seed=3)
+    a = o.make_arch(3)
+    full = G.kernel_build(x, None, a.w_std, a.b_std, get=("nngp",))["nngp"]
+    parts = np.full_like(full, np.nan)
+    for r0, r1 in [(0, 100), (100, 101), (101, 333)]:
+        blk = G.kernel_build(x, None, a.w_std, a.b_std, get=("nngp",), rows=(r0, r1))["nngp"]
+        assert np.isnan(blk[:r0]).all() and np.isnan(blk[r1:]).all()
+        parts[r0:r1] = blk[r0:r1]
+    np.testing.assert_allclose(parts, full, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(full, o.kernel_fn(x, None, "nngp", a), rtol=1e-11)
+
+
+def test_kernel_build_edge_values():
+    a = o.make_arch(1)
+    x = np.array([[1, 2, 3, 4], [4, 3, 2, 1], [0, 0, 0, 1000], [-1, -2, -3, -4], [0, 0, 0, 0], [1, 2, 3, 4]], dtype=np.float64)
+    out = G.kernel_build(x, None, a.w_std, a.b_std)
+    np.testing.assert_allclose(out["nngp"][0, :4], [3.75, 2.7204019972683966, 529.18491951711405, 0.0], rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(out["ntk"][0, :4], [7.5, 4.5511008152653218, 909.49402191888396, 0.0], rtol=1e-13, atol=1e-12)
+    assert np.all(out["nngp"][4] == 0) and np.all(out["ntk"][4] == 0)           # zero vector
+    np.testing.assert_allclose(out["nngp"][0, 5], 3.75, rtol=1e-9)              # duplicate rows: s ~ sqrt(rounding)
+    f32 = G.kernel_build(x, None, a.w_std, a.b_std, dtype=torch.float32)
+    np.testing.assert_allclose(f32["nngp"], out["nngp"], rtol=2e-7, atol=1e-30)
+
+
+def test_kernel_build_empty_inputs():
+    a = o.make_arch(1)
+    out = G.kernel_build(np.zeros((0, 5)), None, a.w_std, a.b_std)
+    assert out["nngp"].shape == (0, 0)
+
+
+# ---------------------------------------------------------------------------- float32 MFMA GEMM
+def test_gemm_exact_on_integers_asymmetric():
+    """A = I against an asymmetric B, then small-integer operands: exact in float32 (catches lane-map swaps)."""
+    torch.manual_seed(0)
+    m, n, k = 256, 384, 128
+    b = torch.randint(-8, 9, (n, k), device=G.dev()).float()
+    a = torch.zeros((m, k), device=G.dev())
+    a[torch.arange(128), torch.arange(128)] = 1.0
+    c = torch.full((m, n), float("nan"), device=G.dev())
+    G.gemm_nt(c, a, b, 1.0, 0.0)
+    assert torch.equal(c[:128], b[:, :128].T.contiguous()) and torch.all(c[128:] == 0)
+    a = torch.randint(-8, 9, (m, k), device=G.dev()).float()
+    c0 = torch.randint(-8, 9, (m, n), device=G.dev()).float()
+    c = c0.clone()
+    G.gemm_nt(c, a, b, -1.0, 1.0)
+    ref = c0.double() - a.double() @ b.double().T
+    assert torch.equal(c.double(), ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 128), (384, 256, 512), (1024, 1024, 2048)])
+def test_gemm_random(m, n, k):
+    torch.manual_seed(1)
+    a = torch.randn((m, k), device=G.dev()); b = torch.randn((n, k), device=G.dev()); c0 = torch.randn((m, n), device=G.dev())
+    c = c0.clone()
+    G.gemm_nt(c, a, b, -1.0, 1.0)
+    ref = c0.double() - a.double() @ b.double().T
+    err = (c.double() - ref).abs().max().item()
+    assert err < 4e-7 * k ** 0.5 * 8, err
+    # strided views (sub-blocks of a larger matrix) and the SYRK form
+    big = torch.randn((m + 128, k + 256), device=G.dev())
+    av = big[128:, 256:]
+    c = torch.zeros((m, m), device=G.dev())
+    G.gemm_nt(c, av, av, 1.0, 0.0, lower_only=True)
+    ref = (av.double() @ av.double().T)
+    tile_lower = (torch.arange(m, device=G.dev())[:, None] // 128) >= (torch.arange(m, device=G.dev())[None, :] // 128)
+    assert ((c.double() - ref).abs()[tile_lower].max().item()) < 4e-7 * k ** 0.5 * 8
+    assert torch.all(c[~tile_lower] == 0)  # tiles above the diagonal are never touched
+
+
+def test_gemm_in_place_inverse_block():
+    torch.manual_seed(2)
+    bmat = torch.randn((512, 128), device=G.dev()); inv = torch.randn((128, 128), device=G.dev())
+    ref = bmat.double() @ inv.double().T
+    G.gemm_nt(bmat, bmat, inv, 1.0, 0.0)
+    assert (bmat.double() - ref).abs().max().item() < 1e-4
+
+
+# ---------------------------------------------------------------------------- Cholesky / TRSM
+def _spd(n, seed, cond_reg=1e-3):
+    x, _ = synth.synthetic_queries(n, 32, seed=seed)
+    K = o.kernel_fn(x / 1000.0, None, "nngp", o.make_arch(1))
+    return K + cond_reg * np.trace(K) / n * np.eye(n)
+
+
+@pytest.mark.parametrize("n", [128, 256, 640, 2048])
+def test_potrf_against_lapack(n):
+    A = _spd(n, n)
+    a = torch.from_numpy(np.tril(A).astype(np.float32)).to(G.dev())
+    a += torch.triu(torch.full((n, n), 7.0, device=G.dev()), 1)  # garbage above the diagonal must be ignored
+    dinv, clamped = G.potrf(a)
+    assert clamped == 0
+    L = torch.tril(a).double().cpu().numpy()
+    Lref = scipy.linalg.cholesky(A.astype(np.float32).astype(np.float64), lower=True)
+    # backward error of the factorisation at float32 level
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) < 5e-6
+    assert G.rel_l2(L, Lref) < 2e-3  # forward error ~ cond * eps32
+    for blk in range(n // 128):
+        Lb = L[blk * 128:(blk + 1) * 128, blk * 128:(blk + 1) * 128]
+        Xb = dinv[blk].double().cpu().numpy()
+        assert np.allclose(np.triu(Xb, 1), 0.0)
+        assert np.abs(Xb @ Lb - np.eye(128)).max() < 2e-3
+
+
+def test_potrf_flags_indefinite():
+    a = torch.eye(128, device=G.dev())
+    a[5, 5] = -1.0
+    _, clamped = G.potrf(a)
+    assert clamped >= 1
+
+
+def test_trsm_right_lower_transposed():
+    n, m = 640, 256
+    A = _spd(n, 11)
+    a = torch.from_numpy(np.tril(A).astype(np.float32)).to(G.dev())
+    dinv, _ = G.potrf(a)
+    torch.manual_seed(3)
+    b = torch.randn((m, n), device=G.dev())
+    x = b.clone()
+    G.trsm(x, a, dinv)
+    L = torch.tril(a).double()
+    resid = (x.double() @ L.T - b.double()).abs().max().item()
+    assert resid < 5e-4, resid
+
+
+# ---------------------------------------------------------------------------- fit / predict (a3, a4)
+def _fit_and_check(x, y, xt, n_relu=1, get="nngp", w=1.0, b=0.0):
+    a = o.make_arch(n_relu, w, b)
+    model = GPModel(x.shape[0], x.shape[1], a.w_std, a.b_std, get=get, diag_reg=1e-3, ny=y.shape[1])
+    model.fit(x, y)
+    info = model.info()
+    post = o.Posterior(x, y, a, diag_reg=1e-3)
+    K = post._factor(get)[0]
+    np.testing.assert_allclose(info["reg"], 1e-3 * np.trace(K) / x.shape[0], rtol=1e-12)
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] <= 1e-10, info
+    alpha = model.alpha().cpu().numpy()
+    assert G.rel_l2(alpha, post._factor(get)[2]) < 1e-6
+    return model, post, info
+
+
+@pytest.mark.parametrize("n,m,d,n_relu", [(100, 7, 20, 1), (128, 128, 64, 1), (700, 130, 64, 3), (1500, 64, 128, 1)])
+def test_fit_predict_nngp(n, m, d, n_relu):
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(m, d, seed=1)
+    model, post, info = _fit_and_check(x, y, xt, n_relu)
+    mean_ref, cov_ref = post.predict(xt, "nngp", True)
+    mean, var = model.predict(xt, cov="diag")
+    l2, elem = G.mean_gate(mean, mean_ref)
+    assert l2 < 1e-6 and elem < 1e-6, (l2, elem, info)
+    np.testing.assert_allclose(var, np.diag(cov_ref), rtol=1e-3, atol=1e-6 * np.abs(cov_ref).max())
+    mean2, cov = model.predict(xt, cov="full")
+    assert np.array_equal(mean2, mean)
+    assert np.abs(cov - cov_ref).max() < 1e-3 * np.abs(np.diag(cov_ref)).max()
+    assert np.array_equal(model.predict(xt, cov=False), mean)
+    # x_test=None: predictions on the training rows (estimator.py:37-40)
+    mean_tr, var_tr = model.predict(None, cov="diag")
+    mtr_ref, ctr_ref = post.predict(None, "nngp", True)
+    assert G.mean_gate(mean_tr, mtr_ref)[0] < 1e-6
+    np.testing.assert_allclose(var_tr, np.diag(ctr_ref), rtol=2e-3, atol=1e-6 * np.abs(ctr_ref).max())
+
+
+def test_fit_predict_ntk_mean_and_two_outputs():
+    x, y = synth.synthetic_queries(300, 64, seed=0)
+    xt, _ = synth.synthetic_queries(50, 64, seed=1)
+    y2 = np.concatenate([y, np.sin(y)], axis=1)
+    model, post, _ = _fit_and_check(x, y2, xt, n_relu=2, get="ntk", w=1.2, b=0.1)
+    mean = model.predict(xt, cov=False)
+    assert mean.shape == (50, 2)
+    assert G.mean_gate(mean, post.predict(xt, "ntk", False))[0] < 1e-6
+
+
+def test_forest_golden_config1(golden_dir):
+    """BASELINE.json configs[0]: forest queries, N=1000 train / 200 test, 3-layer ReLU NNGP."""
+    g = np.load(os.path.join(golden_dir, "forest_n1000_m200.npz"))
+    a = o.make_arch(1)
+    for get in ("nngp", "ntk"):
+        model = GPModel(1000, 20, a.w_std, a.b_std, get=get, diag_reg=1e-3).fit(g["X_train"], g["Y_train"])
+        info = model.info()
+        assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+        if get == "nngp":
+            mean, var = model.predict(g["X_test"], cov="diag")
+            np.testing.assert_allclose(var, g["nngp_var"], rtol=1e-3)
+            _, cov = model.predict(g["X_test"][:16], cov="full")
+            assert np.abs(cov - g["nngp_cov16"]).max() < 1e-3 * np.abs(np.diag(g["nngp_cov16"])).max()
+        else:
+            mean = model.predict(g["X_test"], cov=False)
+        l2, elem = G.mean_gate(mean, g[get + "_mean"])
+        assert l2 < 1e-6 and elem < 1e-5, (get, l2, elem, info)
+        from nngp_src_amd.util import q_error_profile
+        pa, pb = q_error_profile((mean - g["Y_test"]).ravel()), q_error_profile((g[get + "_mean"] - g["Y_test"]).ravel())
+        for key in pa:
+            assert abs(pa[key] - pb[key]) <= 1e-3 * abs(pb[key]), (key, pa[key], pb[key])
+
+
+def test_medium_size_against_c_oracle():
+    """N=4096 (32 Cholesky leaves, deep recursion): posterior means vs the C float64 oracle."""
+    n, m, d = 4096, 256, 64
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(m, d, seed=1)
+    a = o.make_arch(1)
+    ref = c_oracle.fit(x, y, a.w_std, a.b_std)
+    mean_ref, var_ref = c_oracle.predict_nngp(ref, xt, 1)
+    model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
+    info = model.info()
+    mean, var = model.predict(xt, cov="diag")
+    l2, elem = G.mean_gate(mean, mean_ref)
+    assert info["clamped_pivots"] == 0 and l2 < 1e-6 and elem < 1e-6, (l2, elem, info)
+    np.testing.assert_allclose(var, var_ref, rtol=2e-3, atol=1e-6 * np.abs(var_ref).max())
+    assert info["refine_iters"] <= 20, info
+
+
+def test_large_size_properties():
+    """BASELINE configs[1] size (N=8192, d=64): size-independent properties instead of an O(N^3) CPU oracle:
+    float64 residual of the solve, symmetry of K, K alpha + reg alpha = y on a row sample, and linearity in y."""
+    n, d = 8192, 64
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    a = o.make_arch(1)
+    model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
+    info = model.info()
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+    alpha = model.alpha().cpu().numpy()
+    rows = np.arange(0, n, 257)
+    Krows = o.kernel_fn(x[rows], x, "nngp", a)
+    lhs = Krows @ alpha + info["reg"] * alpha[rows]
+    assert np.abs(lhs - y[rows]).max() < 1e-7 * np.abs(y).max()
+    kbuf, ld = model.kernel_buffer()
+    blk = kbuf[:512, :512].cpu().numpy()
+    assert np.array_equal(blk, blk.T)
+    np.testing.assert_allclose(blk[:8], o.kernel_fn(x[:8], x[:512], "nngp", a), rtol=1e-11)
+    mean_tr = model.predict(None, cov=False)
+    np.testing.assert_allclose(mean_tr, y - info["reg"] * alpha, atol=1e-7 * np.abs(y).max())  # K alpha = y - reg alpha
+    model2 = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, 3.0 * y)
+    assert G.rel_l2(model2.alpha().cpu().numpy(), 3.0 * alpha) < 1e-8

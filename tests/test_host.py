@@ -1,0 +1,202 @@
+"""Host-side logic and the C-ABI surface -- no GPU needed (no compute call is made)."""
+import ctypes
+import hashlib
+import io
+import json
+import os
+import re
+import contextlib
+
+import numpy as np
+import pytest
+
+import nngp_src_amd as pkg
+from nngp_src_amd import _lib, encoder as enc, stax, synth, util, distributed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    assert lib.nngp_version() == 1
+    header = open(os.path.join(ROOT, "include", "nngp_hip.h")).read()
+    declared = set(re.findall(r"\b(nngp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"nngp_model"}
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert ctypes.sizeof(_lib.NngpArch) == 8 + 2 * 16 * 8
+    assert ctypes.sizeof(_lib.NngpFitInfo) == 3 * 8 + 2 * 4 + 2 * 8
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    arch = _lib.make_arch([1.0, 1.0], [0.0, 0.0])
+    rc = lib.nngp_kernel_build(None, 4, None, 4, 3, ctypes.byref(arch), 1, None, None, 4, 0, 4, None)
+    assert rc != 0 and b"x1" in lib.nngp_last_error()
+    h = ctypes.c_void_p()
+    rc = lib.nngp_model_create(ctypes.byref(h), 0, 0, 3, 1, ctypes.byref(arch), 1, 1e-3, 0)
+    assert rc != 0 and b"bad sizes" in lib.nngp_last_error()
+    bad = _lib.NngpArch(); bad.n_dense = 0
+    rc = lib.nngp_model_create(ctypes.byref(h), 8, 0, 3, 1, ctypes.byref(bad), 1, 1e-3, 0)
+    assert rc != 0 and b"n_dense" in lib.nngp_last_error()
+    with pytest.raises(_lib.NngpError):
+        _lib.check(rc)
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link or execute anything under oracle/ (and has no CPU fallback)."""
+    src = os.path.join(ROOT, "nngp-src_amd")
+    for dirpath, _, files in os.walk(src):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert not re.search(r"nngp_oracle|c_oracle|libnngp_oracle|oracle/", text), fn
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _, _, kernel_fn = stax.serial(stax.Dense(512), stax.Relu(), stax.Dense(1))
+    with pytest.raises(_lib.NngpError, match="no CPU fallback"):
+        kernel_fn(np.ones((4, 3)), None, "nngp")
+    with pytest.raises(_lib.NngpError):
+        pkg.predict.gradient_descent_mse_ensemble(kernel_fn, np.ones((4, 3)), np.ones((4, 1)), diag_reg=1e-3)(
+            x_test=np.ones((2, 3)), get="nngp", compute_cov=True)
+
+
+def test_stax_topology():
+    init_fn, apply_fn, kernel_fn = stax.serial(stax.Dense(512, W_std=1.5, b_std=0.1), stax.Relu(), stax.Dense(64),
+                                               stax.Relu(), stax.Dense(1))
+    assert kernel_fn.w_std == (1.5, 1.0, 1.0) and kernel_fn.b_std == (0.1, 0.0, 0.0) and kernel_fn.n_relu == 2
+    assert pkg.batch(kernel_fn, device_count=0, batch_size=0) is kernel_fn  # the reference configuration
+    with pytest.raises(NotImplementedError):
+        stax.serial(stax.Relu(), stax.Dense(1))
+    with pytest.raises(NotImplementedError):
+        stax.serial(stax.Dense(4), stax.Dense(1))
+    shape, params = init_fn(0, (10, 7))
+    assert shape == (10, 1) and [w.shape for w, _ in params] == [(7, 512), (512, 64), (64, 1)]
+    assert apply_fn(params, np.ones((10, 7))).shape == (10, 1)
+
+
+def test_finite_width_network_approaches_closed_form():
+    import nngp_oracle as o  # tests may use the oracle as the checker
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 1, size=(5, 6))
+    init_fn, apply_fn, _ = stax.serial(stax.Dense(4096), stax.Relu(), stax.Dense(1))
+    outs = []
+    for seed in range(300):
+        _, params = init_fn(seed, x.shape)
+        outs.append(apply_fn(params, x)[:, 0])
+    emp = np.cov(np.array(outs).T, bias=True)
+    K = o.kernel_fn(x, None, "nngp", o.make_arch(1))
+    assert np.abs(emp - K).max() / np.abs(K).max() < 0.35  # 300 draws: ~10-25 % sampling error
+
+
+def test_encoder_matches_reference_golden(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "encoder_ref.json")))
+    loader = enc.GeneralQueryEncoder()
+    for item in gold["forest"]:
+        pred_list, card = loader.parse_line(item["line"])
+        assert card > 0
+        np.testing.assert_array_equal(loader.transform_to_1d_array(pred_list), np.array(item["x"]))
+    tables = [enc.TableEncoder(t["name"], [enc.ColumnSpec(c[0], c[1], c[2], c[3], int(c[4])) for c in t["columns"]], 64)
+              for t in gold["join_tables"]]
+    je = enc.NNGPEncoder(tables)
+    assert je.join_feat_dim == gold["join_feat_dim"]
+    for item in gold["join"]:
+        np.testing.assert_array_equal(je.parse_line_without_card_then_encode(item["line"]), np.array(item["x"]))
+        tids, preds, joins, card = je.parse_line(item["line"] + "@77")
+        assert card == 77
+    with pytest.raises(AssertionError, match="Query Format Error"):
+        je.parse_line_without_card_then_encode("orders,cust@o_id,1,0")
+
+
+def test_encoder_defaults_and_forest_data(golden_dir):
+    loader = enc.GeneralQueryEncoder()
+    assert loader.total_feat_dim == 20
+    np.testing.assert_array_equal(loader.transform_to_1d_array([]), np.tile([0.0, 1000.0], 10))
+    g = np.load(os.path.join(golden_dir, "forest_queries.npz"))
+    bounds, cards = g["bounds"], g["cards"]
+    assert bounds.shape == (18000, 10, 2) and cards.min() >= 1
+    assert list(g["files"])[:2] == ["query_10.txt", "query_2.txt"]  # sorted(os.listdir) order
+    sent = np.iinfo(np.int32).min
+    q0 = [(c, float(bounds[0, c, 0]), float(bounds[0, c, 1])) for c in range(10) if bounds[0, c, 0] != sent]
+    assert len(q0) == 10  # query_10.txt: ten predicates
+    x0 = loader.transform_to_1d_array(q0)
+    assert (x0 >= 0).all() and (x0 <= 1000).all()
+
+
+def test_join_loader_and_aux_filter(tmp_path):
+    tables = [enc.TableEncoder("a", [enc.numerical("k", 0, 10), enc.numerical("v", 0, 100)], 64),
+              enc.TableEncoder("b", [enc.numerical("k", 0, 10), enc.categorical("c", 70)], 64)]
+    je = enc.NNGPEncoder(tables)
+    assert je.feat_dim == 4 + 2 + 2 + 3
+    (tmp_path / "q1.txt").write_text("a@v,50,10@@100\na,b@@c,1,69@a,b,k@8\n")
+    (tmp_path / "join_query_aux.txt").write_text("a@v,5,1@@4@2.0@0.1\na@v,9,2@@16@500.0@0.1\n")
+    q, cards, infos = je.load_queries(str(tmp_path), use_aux=False)
+    assert cards == [100, 8] and infos[1].num_joins == 1 and infos[1].num_table == 2
+    q, cards, infos = je.load_queries(str(tmp_path), use_aux=True, q_error_threshold=100.0, coef_var_threshold=1.0)
+    assert cards == [16, 100, 8]  # the well-predicted aux line (q_error 2 < 100, cv 0.1 < 1) is dropped
+    X, Y = je.transform_to_arrays(q, cards)
+    assert X.shape == (3, 11) and Y[0, 0] == 4.0
+    np.testing.assert_array_equal(X[2, 6:8], [float(2 ** 62), float(2 ** 58)])  # factorised: MSB-first chunks of 64
+    assert X[2, 10] == 1.0 and X[1, 10] == 0.0
+
+
+def test_split_pin(golden_dir):
+    pin = json.load(open(os.path.join(golden_dir, "split_pin.json")))
+    idx = np.asarray(util.split_indices(pin["n"], pin["seed"]), dtype=np.int64)
+    assert idx[:8].tolist() == [2636, 10465, 12327, 1458, 15087, 17515, 4, 10311] == pin["first"]
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == pin["sha256"]
+    assert pin["sha256"].startswith("9bc86dcff2246369")
+    X = np.arange(40.0).reshape(20, 2); Y = np.arange(20.0).reshape(20, 1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = util.train_test_val_split(X, Y, 0.6, 0.2, all_query_infos=list(range(20)), max_num_train=5)
+    assert out[0].shape == (5, 2) and out[3].shape == (4, 2) and out[6].shape == (4, 2) and len(out[2]) == 5
+
+
+def test_prediction_statistics_format():
+    errors = np.log2(np.array([0.5, 1.0, 2.0, 4.0, 8.0]))
+    infos = [util.QueryInfo(1, 0, p, False, False) for p in (2, 2, 3, 3, 3)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        util.PredictionStatistics().get_prediction_details(errors, infos, partition_keys="num_table")
+    text = buf.getvalue()
+    assert "Query attributes:num_table=1" in text and "# Queries = 5" in text
+    assert "Min/Max: 0.500000000000000 / 8.000000000000000" in text
+    assert "Mean: 3.10000000" in text and "Median: 2.00000000" in text
+    assert "25%/75% Quantiles: 1.00000000 / 4.00000000" in text
+    # more than 6 partitions are merged pairwise (util.py:129-140)
+    infos = [util.QueryInfo(1, 0, p, False, False) for p in range(8)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        util.PredictionStatistics().get_prediction_details(np.zeros(8), infos, partition_keys="num_predicates")
+    assert buf.getvalue().count("Query attributes") == 4 and "# Queries = 2" in buf.getvalue()
+
+
+def test_synthetic_generator_is_deterministic():
+    X, Y = synth.synthetic_queries(256, 64, seed=0)
+    X2, Y2 = synth.synthetic_queries(256, 64, seed=0)
+    assert np.array_equal(X, X2) and np.array_equal(Y, Y2)
+    assert hashlib.sha256(X.tobytes()).hexdigest()[:16] == synth_pin()
+    assert X.min() >= 0 and X.max() <= 1000 and (X[:, 0::2] >= 0).all()
+    active = X[:, 1::2] != 1000.0
+    assert active.sum(axis=1).min() >= 1 and active.sum(axis=1).max() <= 10
+    assert (X[:, 0::2] >= np.where(active, X[:, 1::2], 0)).all()  # upper >= lower on active pairs
+    assert 0 <= Y.min() and Y.max() <= 19.2
+    Xj, _ = synth.synthetic_queries(64, 256, seed=1, join_block=True)
+    assert set(np.unique(Xj[:, 256 - 96:][:, 2::3])) <= {0.0, 1.0}
+
+
+def synth_pin():
+    return "618243c2ba9827d5"
+
+
+def test_row_partition():
+    for n, w in [(1000, 8), (128, 3), (7, 8), (65536, 8)]:
+        parts = [distributed.row_partition(n, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert all(r1 - r0 <= distributed.row_chunk(n, w) for r0, r1 in parts)
