@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- NNGP kernel-build + GP-solve on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one synthetic batch of encoded queries already
+resident in HBM: row norms + regulariser, N x N kernel build, float32 MFMA Cholesky, CG solve for alpha
+on the float64 kernel, and the posterior (cross kernel, mean, diag variance) for M test queries.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the kernel build is sharded by row
+block, one all-gather makes K whole on every rank, factor/solve are replicated, test rows are sharded
+("strong" scaling: the problem is fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    # name: (N, d, n_relu, get, M, join_block, description)  -- BASELINE.json configs, SURVEY.md 8d
+    "cfg1": (1000, 20, 1, "nngp", 200, False, "forest-like N=1000/M=200, d=20, 3-layer ReLU NNGP (configs[0] shape, synthetic rows)"),
+    "cfg2": (8192, 64, 1, "nngp", 1024, False, "synthetic N=8192, d=64, 3-layer ReLU NNGP (configs[1])"),
+    "cfg3": (32768, 128, 3, "nngp", 1024, False, "synthetic N=32768, d=128, 5-layer ReLU NNGP + full Cholesky posterior (configs[2], north-star target)"),
+    "cfg4": (65536, 128, 3, "nngp", 1024, False, "synthetic N=65536, d=128, row-block kernel shard + all-gather (configs[3])"),
+    "cfg5": (16384, 256, 1, "ntk", 1024, True, "synthetic join encoding N=16384, d=256, NTK (configs[4]; mean only)"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def flop_model(n, d, m, n_relu):
+    """Algorithmic work of one step."""
+    f_k = n * (n + 1) * d
+    f_c = n ** 3 / 3 + n ** 2 / 2 + n / 6
+    f_solve = 2 * n * n
+    f_post = 2 * n * m * d + 2 * n * m + n * n * m + 2 * n * m
+    return {"kernel_build": f_k, "cholesky": f_c, "alpha_solve": f_solve, "posterior": f_post,
+            "total": f_k + f_c + f_solve + f_post, "relu_maps": n_relu * n * (n + 1) // 2}
+
+
+def cpu_baseline(n_relu, get):
+    """The C float64/OpenMP oracle ("port") on a bounded sample of the same workload, host cores of this box."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    from nngp_src_amd import synth
+    n, d, m = 6144, 128, 256
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(m, d, seed=1)
+    w, b = [1.0] * (n_relu + 1), [0.0] * (n_relu + 1)
+    c_oracle.kernel_build(x[:256], None, "nngp", w, b)  # warm the thread pool
+    t0 = time.perf_counter()
+    model = c_oracle.fit(x, y, w, b, get="nngp")
+    c_oracle.predict_nngp(model, xt, 1)
+    dt = time.perf_counter() - t0
+    fl = flop_model(n, d, m, n_relu)
+    return {"value": round(fl["total"] / dt / 1e9, 3), "unit": "GFLOP/s", "cores": c_oracle.num_threads(), "kind": "port",
+            "sample": "same step at N=%d, d=%d, M=%d, n_relu=%d, float64 C/OpenMP oracle: %.2f s (build %.2f, potrf %.2f)"
+                      % (n, d, m, n_relu, dt, model["stage_sec"][0], model["stage_sec"][1]),
+            "ms": round(dt * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nngp_src_amd import distributed, synth
+    from nngp_src_amd.model import GPModel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    n, d, n_relu, get, m, join_block, desc = CONFIGS[args.config]
+    x, y = synth.synthetic_queries(n, d, seed=0, join_block=join_block)
+    xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
+    xd, yd, xtd = (torch.from_numpy(a).to(dev) for a in (x, y, xt))
+    m0, m1 = distributed.row_partition(m, world, rank)
+    xt_local = xtd[m0:m1].contiguous()
+    w_std, b_std = [1.0] * (n_relu + 1), [0.0] * (n_relu + 1)
+    n_cap = distributed.row_chunk(n, world) * world
+    model = GPModel(n_cap, d, w_std, b_std, get=get, diag_reg=1e-3, m_cap=max(m1 - m0, 1))
+    cov = "diag" if get == "nngp" else False
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def step(stages=None):
+        e0 = ev()
+        model.set_train(xd, yd)
+        e1 = ev()
+        r0, r1 = distributed.row_partition(n, world, rank)
+        model.build_rows(0, n) if world == 1 else model.build_rows(r0, r1)
+        e2 = ev()
+        if world > 1:
+            buf, _ = model.kernel_buffer(all_rows=True)
+            distributed.allgather_rows(buf, n)
+        e3 = ev()
+        model.factor()
+        e4 = ev()
+        model.solve()
+        e5 = ev()
+        out = model.predict(xt_local, cov=cov, as_numpy=False) if m1 > m0 else None
+        e6 = ev()
+        if stages is not None:
+            torch.cuda.synchronize()
+            for k, (a, b) in {"set_train": (e0, e1), "kernel_build": (e1, e2), "allgather": (e2, e3),
+                              "cholesky": (e3, e4), "alpha_solve": (e4, e5), "posterior": (e5, e6)}.items():
+                stages.setdefault(k, []).append(a.elapsed_time(b))
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stages = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(stages)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = model.info()
+    if rank == 0:
+        fl = flop_model(n, d, m, n_relu)
+        ms = elapsed / args.steps * 1e3
+        st = {k: float(np.mean(v)) for k, v in stages.items()}
+        chol_tflops = fl["cholesky"] / (st["cholesky"] * 1e-3) / 1e12
+        result = {
+            "metric": "NNGP kernel-build + GP-solve wall-clock (ms) and GFLOP/s at N train queries",
+            "value": round(fl["total"] / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": m,
+                       "parallelism": "row-block kernel shard x%d + all-gather, replicated Cholesky" % world if world > 1 else "single GPU",
+                       "precision": "float64 kernel build + CG residual, float32 MFMA Cholesky (preconditioner), float64 means"},
+            "roofline": {"bound": "mfma", "achieved": round(chol_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(chol_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "Cholesky stage (k_gemm_nt_f32 SYRK/GEMM launches + k_potrf_leaf), F_C = N^3/3 + N^2/2 + N/6 per step",
+                         "north_star_frac_build_plus_cholesky": round((fl["kernel_build"] + fl["cholesky"]) /
+                                                                       ((st["kernel_build"] + st["cholesky"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "stages_ms": {k: round(v, 3) for k, v in st.items()},
+            "fit_info": {"cg_iters": info["refine_iters"], "rel_residual": info["rel_residual"],
+                         "clamped_pivots": info["clamped_pivots"], "reg": info["reg"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(n_relu, get)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

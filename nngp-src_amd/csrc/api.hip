@@ -173,9 +173,11 @@ int nngp_kernel_build(const double* x1, int64_t n1, const double* x2, int64_t n2
     hipStream_t s = (hipStream_t)stream;
     ArchDev ad;
     NNGP_TRY(make_arch_dev(arch, &ad));
-    NNGP_REQUIRE(x1 != nullptr && n1 >= 0 && d > 0, "kernel_build: bad x1/n1/d");
     const bool sym = (x2 == nullptr);
     if (sym) n2 = n1;
+    NNGP_REQUIRE(n1 >= 0 && n2 >= 0 && d > 0, "kernel_build: bad n1/n2/d");
+    if (n1 == 0 || n2 == 0) return 0;  // empty inputs: nothing to write
+    NNGP_REQUIRE(x1 != nullptr, "kernel_build: x1 is NULL");
     NNGP_REQUIRE(n2 >= 0 && ld >= n2, "kernel_build: ld (%lld) < n2 (%lld)", (long long)ld, (long long)n2);
     NNGP_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n1, "kernel_build: bad row range");
     NNGP_REQUIRE(out_dtype == NNGP_DTYPE_F32 || out_dtype == NNGP_DTYPE_F64, "kernel_build: bad out_dtype");
@@ -299,7 +301,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
 int nngp_model_factor(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
-    NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, s));
+    NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
     NNGP_TRY(potrf_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), s));

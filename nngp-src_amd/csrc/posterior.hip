@@ -13,7 +13,7 @@ namespace {
 // grid = (ceil(np/1024), np); each workgroup converts up to 1024 columns of one row.
 __global__ __launch_bounds__(256) void k_factor_input(const double* __restrict__ k64, int64_t ld64,
                                                       float* __restrict__ a32, int64_t ld32, int64_t n, int64_t np,
-                                                      double reg, int64_t row0) {
+                                                      double reg, double pad_diag, int64_t row0) {
     const int64_t row = row0 + blockIdx.y;
     const int64_t c0 = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
     const int64_t row_tile_end = (row / TB + 1) * TB;  // columns < this belong to tiles on/below the diagonal
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_factor_input(const double* __restrict__
             t = k64[row * ld64 + c];
             if (c == row) t += reg;
         } else {
-            t = (c == row) ? 1.0 : 0.0;
+            t = (c == row) ? pad_diag : 0.0;  // decoupled padding block, scaled like a real diagonal entry
         }
         v[e] = (float)t;
     }
@@ -83,13 +83,13 @@ __global__ void k_strided_copy(const double* src, int64_t incs, double* dst, int
 }  // namespace
 
 int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np, double reg,
-                        hipStream_t s) {
+                        double pad_diag, hipStream_t s) {
     NNGP_REQUIRE(np % TB == 0 && np <= 65535LL * 1024, "factor_input: bad padded size %lld", (long long)np);
     // grid.y is limited to 65535 rows per launch
     for (int64_t r0 = 0; r0 < np; r0 += 65535) {
         const int64_t rows = (np - r0 < 65535) ? np - r0 : 65535;
         hipLaunchKernelGGL(k_factor_input, dim3((unsigned)((np + 1023) / 1024), (unsigned)rows), dim3(256), 0, s,
-                           k64, ld64, a32, ld32, n, np, reg, r0);
+                           k64, ld64, a32, ld32, n, np, reg, pad_diag, r0);
     }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;

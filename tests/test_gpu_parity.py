@@ -104,6 +104,33 @@ def test_gemm_exact_on_integers_asymmetric():
     assert torch.equal(c.double(), ref)
 
 
+def test_gemm_is_a_k_ordered_fp32_fma_chain():
+    """f32-input MFMA is an exact fp32 fma chain (guide: MFMA numerics); emulate the kernel's k order on the host
+    and require bit-for-bit equality.  Order: per 32-wide K tile, per 8-wide step s, per kk: k = 8s+kk then 8s+4+kk."""
+    torch.manual_seed(5)
+    m = n = 128
+    k = 256
+    a = torch.randn((m, k), device=G.dev()); b = torch.randn((n, k), device=G.dev())
+    c = torch.zeros((m, n), device=G.dev())
+    G.gemm_nt(c, a, b, 1.0, 0.0)
+    got = c.cpu().numpy()
+    an, bn = a.cpu().numpy(), b.cpu().numpy()
+
+    def chain(order):
+        acc = np.zeros((m, n), dtype=np.float32)
+        for kk in order:
+            prod = an[:, kk].astype(np.float64)[:, None] * bn[:, kk].astype(np.float64)[None, :]  # exact in f64
+            acc = (acc.astype(np.float64) + prod).astype(np.float32)                               # one rounding (fma)
+        return acc
+
+    base = [32 * t + 8 * s + kk + 4 * h for t in range(k // 32) for s in range(4) for kk in range(4) for h in (0, 1)]
+    alt = [32 * t + 8 * s + kk + 4 * h for t in range(k // 32) for s in range(4) for kk in range(4) for h in (1, 0)]
+    ok = np.array_equal(got, chain(base)) or np.array_equal(got, chain(alt))
+    if not ok:
+        d0 = np.abs(got - chain(base)).max()
+        pytest.fail("GEMM is not bit-identical to the emulated fma chain (max diff %g)" % d0)
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 128), (384, 256, 512), (1024, 1024, 2048)])
 def test_gemm_random(m, n, k):
     torch.manual_seed(1)
@@ -111,8 +138,8 @@ def test_gemm_random(m, n, k):
     c = c0.clone()
     G.gemm_nt(c, a, b, -1.0, 1.0)
     ref = c0.double() - a.double() @ b.double().T
-    err = (c.double() - ref).abs().max().item()
-    assert err < 4e-7 * k ** 0.5 * 8, err
+    bound = c0.abs().double() + a.abs().double() @ b.abs().double().T   # sum |terms| per element
+    assert ((c.double() - ref).abs() <= 1e-6 * bound).all(), ((c.double() - ref).abs() / bound).max().item()
     # strided views (sub-blocks of a larger matrix) and the SYRK form
     big = torch.randn((m + 128, k + 256), device=G.dev())
     av = big[128:, 256:]
@@ -120,7 +147,8 @@ def test_gemm_random(m, n, k):
     G.gemm_nt(c, av, av, 1.0, 0.0, lower_only=True)
     ref = (av.double() @ av.double().T)
     tile_lower = (torch.arange(m, device=G.dev())[:, None] // 128) >= (torch.arange(m, device=G.dev())[None, :] // 128)
-    assert ((c.double() - ref).abs()[tile_lower].max().item()) < 4e-7 * k ** 0.5 * 8
+    bound = av.abs().double() @ av.abs().double().T
+    assert ((c.double() - ref).abs() <= 1e-6 * bound)[tile_lower].all()
     assert torch.all(c[~tile_lower] == 0)  # tiles above the diagonal are never touched
 
 
@@ -212,7 +240,8 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     mean_tr, var_tr = model.predict(None, cov="diag")
     mtr_ref, ctr_ref = post.predict(None, "nngp", True)
     assert G.mean_gate(mean_tr, mtr_ref)[0] < 1e-6
-    np.testing.assert_allclose(var_tr, np.diag(ctr_ref), rtol=2e-3, atol=1e-6 * np.abs(ctr_ref).max())
+    # on the training rows the posterior variance is a small difference of large numbers: float32 solve -> 1e-2
+    np.testing.assert_allclose(var_tr, np.diag(ctr_ref), rtol=1e-2, atol=1e-6 * np.abs(ctr_ref).max())
 
 
 def test_fit_predict_ntk_mean_and_two_outputs():
