@@ -93,7 +93,7 @@ int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, v
  *               (0, n) takes the symmetric path (lower tiles computed once, mirrored)
  *   factor    : A32 = float32(K) + reg I, blocked lower Cholesky on float32 MFMA, in place
  *   solve     : alpha = (K + reg I)^-1 Y by CG on the float64 kernel, preconditioned by the
- *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-12)       */
+ *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-10)       */
 int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_t n, void* stream);
 int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, void* stream);
 int nngp_model_factor(nngp_model* m, void* stream);

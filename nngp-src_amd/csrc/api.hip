@@ -72,6 +72,7 @@ struct nngp_model {
     int32_t* clamped = nullptr;
     double* alpha = nullptr;  // [n_cap, ny]
     PcgWork pcg{};
+    TriInv tri{};
 
     // predict-side buffers (grown on demand when m > m_cap)
     double* xt_q = nullptr;      // [m_cap]
@@ -92,6 +93,7 @@ struct nngp_model {
         dev_free(pcg.r); dev_free(pcg.z); dev_free(pcg.p); dev_free(pcg.q); dev_free(pcg.xcol); dev_free(pcg.bcol);
         dev_free(pcg.f32a); dev_free(pcg.f32b); dev_free(pcg.f32c); dev_free(pcg.scal);
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
+        dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(ktt64); dev_free(vvt32);
     }
 };
@@ -239,6 +241,12 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     A(dev_alloc(&m->pcg.xcol, np)); A(dev_alloc(&m->pcg.bcol, np));
     A(dev_alloc(&m->pcg.f32a, np)); A(dev_alloc(&m->pcg.f32b, np)); A(dev_alloc(&m->pcg.f32c, np));
     A(dev_alloc(&m->pcg.scal, 8));
+    {
+        const int64_t bs_cap = triinv_block(np);
+        const int64_t nblk = (np + bs_cap - 1) / bs_cap;
+        A(dev_alloc(&m->tri.tinv, nblk * bs_cap * bs_cap)); A(dev_alloc(&m->tri.xinv, nblk * bs_cap * bs_cap));
+        A(dev_alloc(&m->tri.partial, (bs_cap / TB) * np)); A(dev_alloc(&m->tri.tmp, bs_cap));
+    }
     if (rc == 0 && hipHostMalloc(reinterpret_cast<void**>(&m->pcg.host_scal), sizeof(double) * 8) != hipSuccess) {
         set_error("model_create: hipHostMalloc failed");
         rc = -1;
@@ -305,6 +313,8 @@ int nngp_model_factor(nngp_model* m, void* stream) {
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
     NNGP_TRY(potrf_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), s));
+    m->tri.bs = triinv_block(m->np);
+    NNGP_TRY(triinv_build(m->a32, m->np, m->dinv, m->np, m->tri, s));
     m->factored = true;
     m->solved = false;
     return 0;
@@ -314,14 +324,14 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->factored, "solve: factor first");
     if (max_iters <= 0) max_iters = 60;
-    if (tol <= 0.0) tol = 1e-12;
+    if (tol <= 0.0) tol = 1e-10;
     m->iters = 0;
     m->relres = 0.0;
     for (int c = 0; c < m->ny; ++c) {
         NNGP_TRY(launch_strided_copy_f64(m->y + c, m->ny, m->pcg.bcol, 1, m->n, s));
         int it = 0;
         double rr = 0.0;
-        NNGP_TRY(pcg_solve(m->k64, m->np, m->n, m->reg, m->a32, m->np, m->dinv, m->np, m->pcg.bcol, m->pcg.xcol,
+        NNGP_TRY(pcg_solve(m->k64, m->np, m->n, m->reg, m->a32, m->np, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
                            m->pcg, max_iters, tol, &it, &rr, s));
         NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
         if (it > m->iters) m->iters = it;

@@ -74,6 +74,10 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s);
 int launch_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
                        int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s);
 
+int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
+                               int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int batch,
+                               int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s);
+
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
 int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s);
@@ -81,9 +85,19 @@ int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, 
                  hipStream_t s);
 
 // ---- solve.hip ----
-// z = L^-1 r (forward) then w = L^-T z (backward), float32 factor with inverted 128-blocks.
-int trsv_forward_f32(const float* l, int64_t ld, const float* dinv, int64_t n, float* b, float* x, hipStream_t s);
-int trsv_backward_f32(const float* l, int64_t ld, const float* dinv, int64_t n, float* b, float* x, hipStream_t s);
+// Inverted diagonal blocks (size bs) of the float32 factor for the blocked triangular solves.
+struct TriInv {
+    int64_t bs = 0;
+    float* tinv = nullptr;     // [nblk][bs*bs]  T_J = L_JJ^-T (upper triangular)
+    float* xinv = nullptr;     // [nblk][bs*bs]  X_J = L_JJ^-1 (lower triangular)
+    float* partial = nullptr;  // [bs/128][np]   column partial sums of the backward sweep
+    float* tmp = nullptr;      // [bs]
+};
+int64_t triinv_block(int64_t np);
+int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, hipStream_t s);
+// in-place solves L x = b / L^T x = b on a float32 vector of length np
+int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);
+int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);
 int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, const double* x, int64_t incx,
                     double* y, int64_t incy, double diag_add, hipStream_t s);
 struct PcgWork {
@@ -93,7 +107,7 @@ struct PcgWork {
     double* host_scal;  // pinned host [8]
 };
 int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
-              const float* dinv, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
+              const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
               double tol, int* iters_out, double* relres_out, hipStream_t s);
 
 // ---- posterior.hip ----

@@ -25,8 +25,7 @@ namespace nngp {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int STAGE_FLOATS = (BM + BN) * BK;  // 8192 floats = 32 KiB per stage
+constexpr int BK = 32;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,10 +33,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // byte offset of logical 16-byte chunk `ch` (0..7) of row `row` inside a [rows][32 floats] LDS image
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
-template <bool LOWER>
+// Workgroup tile = (64*WM) x (64*WN): 4 waves in a 2x2 grid, each wave WM x WN accumulators of 32x32.
+//   <2,2> 128x128  the throughput shape (big SYRK / GEMM)
+//   <1,2>  64x128  in-place multiplication by an inverted diagonal block with few row tiles
+//   <1,1>  64x64   small problems: 4x the workgroups, a quarter of the serial MFMA chain per workgroup
+template <int WM, int WN, bool LOWER>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, const float* A, int64_t lda,
                                                         const float* B, int64_t ldb, int tiles_n, int nk,
-                                                        float alpha, float beta) {
+                                                        float alpha, float beta, int64_t sc, int64_t sa,
+                                                        int64_t sb) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int STAGE_FLOATS = (BM + BN) * BK;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -54,37 +60,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
         bi = blockIdx.x / tiles_n;
         bj = blockIdx.x % tiles_n;
     }
-    const float* Ab = A + (int64_t)bi * BM * lda;
-    const float* Bb = B + (int64_t)bj * BN * ldb;
+    // batched form: blockIdx.y selects one of several independent problems at constant strides
+    C += (int64_t)blockIdx.y * sc;
+    const float* Ab = A + (int64_t)blockIdx.y * sa + (int64_t)bi * BM * lda;
+    const float* Bb = B + (int64_t)blockIdx.y * sb + (int64_t)bj * BN * ldb;
 
-    // global -> register staging: 4 chunks of A and 4 of B per thread (chunk = 16 bytes = 4 k)
-    f32x4 ga[4], gb[4];
+    // global -> register staging: 16-byte chunks (4 k), 8 chunks per 128-byte row
+    f32x4 ga[BM / 32], gb[BN / 32];
     const int ld_row = tid >> 3, ld_ch = tid & 7;  // + 32 rows per e
     auto load_tile = [&](int t) {
         const int64_t k0 = (int64_t)t * BK + ld_ch * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = ld_row + 32 * e;
-            ga[e] = *reinterpret_cast<const f32x4*>(Ab + (int64_t)row * lda + k0);
-            gb[e] = *reinterpret_cast<const f32x4*>(Bb + (int64_t)row * ldb + k0);
-        }
+        for (int e = 0; e < BM / 32; ++e)
+            ga[e] = *reinterpret_cast<const f32x4*>(Ab + (int64_t)(ld_row + 32 * e) * lda + k0);
+#pragma unroll
+        for (int e = 0; e < BN / 32; ++e)
+            gb[e] = *reinterpret_cast<const f32x4*>(Bb + (int64_t)(ld_row + 32 * e) * ldb + k0);
     };
     auto store_tile = [&](int buf) {
-        char* sa = reinterpret_cast<char*>(smem + buf * STAGE_FLOATS);
-        char* sb = sa + BM * BK * 4;
+        char* sa_ = reinterpret_cast<char*>(smem + buf * STAGE_FLOATS);
+        char* sb_ = sa_ + BM * BK * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = ld_row + 32 * e;
-            *reinterpret_cast<f32x4*>(sa + lds_off(row, ld_ch)) = ga[e];
-            *reinterpret_cast<f32x4*>(sb + lds_off(row, ld_ch)) = gb[e];
-        }
+        for (int e = 0; e < BM / 32; ++e) *reinterpret_cast<f32x4*>(sa_ + lds_off(ld_row + 32 * e, ld_ch)) = ga[e];
+#pragma unroll
+        for (int e = 0; e < BN / 32; ++e) *reinterpret_cast<f32x4*>(sb_ + lds_off(ld_row + 32 * e, ld_ch)) = gb[e];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -95,24 +101,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         if (t + 1 < nk) load_tile(t + 1);
-        const char* sa = reinterpret_cast<const char*>(smem + (t & 1) * STAGE_FLOATS);
-        const char* sb = sa + BM * BK * 4;
+        const char* sa_ = reinterpret_cast<const char*>(smem + (t & 1) * STAGE_FLOATS);
+        const char* sb_ = sa_ + BM * BK * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            f32x4 fa[2], fb[2];
+            f32x4 fa[WM], fb[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ra = wm * 64 + i * 32 + frow;
-                const int rb = wn * 64 + i * 32 + frow;
-                fa[i] = *reinterpret_cast<const f32x4*>(sa + lds_off(ra, 2 * s + fh));
-                fb[i] = *reinterpret_cast<const f32x4*>(sb + lds_off(rb, 2 * s + fh));
-            }
+            for (int i = 0; i < WM; ++i)
+                fa[i] = *reinterpret_cast<const f32x4*>(sa_ + lds_off(wm * 32 * WM + i * 32 + frow, 2 * s + fh));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                fb[j] = *reinterpret_cast<const f32x4*>(sb_ + lds_off(wn * 32 * WN + j * 32 + frow, 2 * s + fh));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < nk) store_tile((t + 1) & 1);
@@ -120,12 +125,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
     }
 
     // epilogue: acc[i][j][r] is element (row, col) with row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
-    const int64_t row_base = (int64_t)bi * BM + wm * 64;
-    const int64_t col_base = (int64_t)bj * BN + wn * 64;
+    const int64_t row_base = (int64_t)bi * BM + wm * 32 * WM;
+    const int64_t col_base = (int64_t)bj * BN + wn * 32 * WN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WN; ++j) {
             float* p0 = C + (row_base + i * 32 + 4 * fh) * ldc + col_base + j * 32 + frow;
             float cold[16];
             if (beta != 0.0f) {  // issue all 16 loads of the sub-tile before the first use
@@ -141,34 +146,59 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
         }
 }
 
+template <int WM, int WN, bool LOWER>
+int launch_variant(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
+                   int64_t n, int64_t k, float alpha, float beta, int batch, int64_t sc, int64_t sa, int64_t sb,
+                   hipStream_t s) {
+    const int64_t tm = m / (64 * WM), tn = n / (64 * WN);
+    const int64_t nb = LOWER ? tm * (tm + 1) / 2 : tm * tn;
+    NNGP_REQUIRE(nb < (LOWER ? 16000000LL : 2147483647LL), "gemm_nt_f32: grid too large");
+    hipLaunchKernelGGL((k_gemm_nt_f32<WM, WN, LOWER>), dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, s, c, ldc, a,
+                       lda, b, ldb, (int)tn, (int)(k / BK), alpha, beta, sc, sa, sb);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
-int launch_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
-                       int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s) {
-    if (m <= 0 || n <= 0) return 0;
-    NNGP_REQUIRE(m % BM == 0 && n % BN == 0 && k % 128 == 0 && k > 0,
+int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
+                               int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int batch,
+                               int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s) {
+    if (m <= 0 || n <= 0 || batch <= 0) return 0;
+    NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % 128 == 0 && k > 0,
                  "gemm_nt_f32: dims must be multiples of 128 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n,
                  (long long)k);
     NNGP_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
-                     ((uintptr_t)c & 3) == 0,
+                     ((uintptr_t)c & 3) == 0 && stride_a % 4 == 0 && stride_b % 4 == 0,
                  "gemm_nt_f32: operands must be 16-byte aligned");
     NNGP_REQUIRE(lda >= k && ldb >= k && ldc >= n, "gemm_nt_f32: leading dimension too small");
-    const int64_t tm = m / BM, tn = n / BN;
-    const int nk = (int)(k / BK);
+    NNGP_REQUIRE(batch <= 65535, "gemm_nt_f32: batch too large");
+    // Tile choice: a 128x128 workgroup runs its K loop as one serial MFMA chain on one CU, so problems with few
+    // tiles use smaller workgroup tiles to spread over more of the 256 CUs.
+    const int64_t t128 = (lower_only ? (m / 128) * (m / 128 + 1) / 2 : (m / 128) * (n / 128)) * batch;
+    const bool in_place = (c == a);  // C aliases A: legal only with a single column tile per row block (n == 128)
+    if (in_place) NNGP_REQUIRE(n == 128 && beta == 0.0f, "gemm_nt_f32: in-place form needs n == 128 and beta == 0");
     if (lower_only) {
         NNGP_REQUIRE(m == n, "gemm_nt_f32: lower_only needs a square result");
-        const int64_t nb = tm * (tm + 1) / 2;
-        NNGP_REQUIRE(nb < 16000000, "gemm_nt_f32: grid too large");  // float sqrt decode stays exact-correctable
-        hipLaunchKernelGGL(k_gemm_nt_f32<true>, dim3((unsigned)nb), dim3(256), 0, s, c, ldc, a, lda, b, ldb, (int)tn,
-                           nk, alpha, beta);
-    } else {
-        const int64_t nb = tm * tn;
-        NNGP_REQUIRE(nb < 2147483647LL, "gemm_nt_f32: grid too large");
-        hipLaunchKernelGGL(k_gemm_nt_f32<false>, dim3((unsigned)nb), dim3(256), 0, s, c, ldc, a, lda, b, ldb, (int)tn,
-                           nk, alpha, beta);
+        if (t128 >= 192)
+            return launch_variant<2, 2, true>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
+                                              stride_b, s);
+        return launch_variant<1, 1, true>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
+                                          stride_b, s);
     }
-    NNGP_HIP_CHECK(hipGetLastError());
-    return 0;
+    if (t128 >= 192)
+        return launch_variant<2, 2, false>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
+                                           stride_b, s);
+    if (in_place || t128 >= 96)
+        return launch_variant<1, 2, false>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
+                                           stride_b, s);
+    return launch_variant<1, 1, false>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
+                                       stride_b, s);
+}
+
+int launch_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
+                       int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s) {
+    return launch_gemm_nt_f32_batched(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only, 1, 0, 0, 0, s);
 }
 
 }  // namespace nngp

@@ -68,10 +68,27 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        Ls[r * LS + c] = (c <= r) ? A[(int64_t)r * ld + c] : 0.0f;
-        Xs[r * LS + c] = 0.0f;
+    {
+        // 16 independent 16-byte loads per thread, issued back to back (one HBM round trip for the whole block)
+        float4 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int idx = (tid + 256 * e) * 4;
+            const int r = idx >> 7, c = idx & 127;
+            v[e] = (c <= r) ? *reinterpret_cast<const float4*>(A + (int64_t)r * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int idx = (tid + 256 * e) * 4;
+            const int r = idx >> 7, c = idx & 127;
+            float* lp = Ls + r * LS + c;
+            float* xp = Xs + r * LS + c;
+            lp[0] = v[e].x;
+            lp[1] = (c + 1 <= r) ? v[e].y : 0.0f;
+            lp[2] = (c + 2 <= r) ? v[e].z : 0.0f;
+            lp[3] = (c + 3 <= r) ? v[e].w : 0.0f;
+            xp[0] = xp[1] = xp[2] = xp[3] = 0.0f;
+        }
     }
     __syncthreads();
 
@@ -165,10 +182,19 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
         __syncthreads();
     }
 
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int idx = (tid + 256 * e) * 4;
         const int r = idx >> 7, c = idx & 127;
-        if (c <= r) A[(int64_t)r * ld + c] = Ls[r * LS + c];
-        dinv[idx] = Xs[r * LS + c];
+        const float* lp = Ls + r * LS + c;
+        const float* xp = Xs + r * LS + c;
+        if (c + 3 <= r) {
+            *reinterpret_cast<float4*>(A + (int64_t)r * ld + c) = make_float4(lp[0], lp[1], lp[2], lp[3]);
+        } else if (c <= r) {  // the 4-wide group straddles the diagonal: keep the caller's upper entries
+            for (int k = 0; k < 4; ++k)
+                if (c + k <= r) A[(int64_t)r * ld + c + k] = lp[k];
+        }
+        *reinterpret_cast<float4*>(dinv + idx) = make_float4(xp[0], xp[1], xp[2], xp[3]);
     }
     if (wave == 0 && lane == 0 && nclamp > 0 && clamped != nullptr) atomicAdd(clamped, nclamp);
 }

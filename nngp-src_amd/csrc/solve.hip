@@ -12,89 +12,75 @@ namespace nngp {
 
 namespace {
 
-// ---- forward: x_j = Linv_jj b_j ; b[i] -= L[i, blk j] x_j for rows below ----
-// grid.x = 1 + number of 256-row chunks below block j; every workgroup recomputes x_j (128x128 matvec
-// from L2-resident data), workgroup 0 stores it, workgroups >= 1 update their chunk of b.
-__global__ __launch_bounds__(256) void k_trsv_fwd_step(const float* __restrict__ L, int64_t ld,
-                                                       const float* __restrict__ dinv_j, int64_t jrow,
-                                                       int64_t n, float* __restrict__ b, float* __restrict__ x) {
-    __shared__ float bj[TB];
-    __shared__ float xj[TB];
-    const int tid = threadIdx.x;
-    if (tid < TB) bj[tid] = b[jrow + tid];
-    __syncthreads();
-    {
-        // two threads per output row: halves of the 128-long dot product
-        const int r = tid >> 1, half = tid & 1;
-        const float4* dr = reinterpret_cast<const float4*>(dinv_j + r * TB + half * 64);
-        float s = 0.0f;
-#pragma unroll 4
-        for (int c = 0; c < 16; ++c) {
-            const float4 v = dr[c];
-            const float* bp = bj + half * 64 + c * 4;
-            s = fmaf(v.x, bp[0], s);
-            s = fmaf(v.y, bp[1], s);
-            s = fmaf(v.z, bp[2], s);
-            s = fmaf(v.w, bp[3], s);
-        }
-        s += __shfl_xor(s, 1);
-        if (half == 0) xj[r] = s;
+// ---- float32 GEMV building blocks of the blocked triangular solves ----
+// y[r] = dot(A[r,:], x)  (sub = 0)   or   y[r] -= dot(A[r,:], x)  (sub = 1); one wave per row, cols % 4 == 0
+__global__ __launch_bounds__(256) void k_gemv_n_f32(const float* __restrict__ A, int64_t lda, int64_t rows,
+                                                    int64_t cols, const float* __restrict__ x, float* y, int sub) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* ar = reinterpret_cast<const float4*>(A + row * lda);
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    float s = 0.0f;
+    for (int64_t c = lane; c < cols / 4; c += 64) {
+        const float4 a = ar[c], v = xv[c];
+        s = fmaf(a.x, v.x, s);
+        s = fmaf(a.y, v.y, s);
+        s = fmaf(a.z, v.z, s);
+        s = fmaf(a.w, v.w, s);
     }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid < TB) x[jrow + tid] = xj[tid];
-        return;
-    }
-    // update rows: 32 lanes x float4 cover the 128 columns of one row; a wave does 2 rows per pass
-    const int lane = tid & 63, wave = tid >> 6;
-    const int sub = lane >> 5, l32 = lane & 31;
-    const float4 xv = make_float4(xj[l32 * 4], xj[l32 * 4 + 1], xj[l32 * 4 + 2], xj[l32 * 4 + 3]);
-    const int64_t chunk0 = jrow + TB + (int64_t)(blockIdx.x - 1) * 256;
-    for (int it = 0; it < 32; ++it) {
-        const int64_t row = chunk0 + wave * 64 + it * 2 + sub;
-        float s = 0.0f;
-        if (row < n) {
-            const float4 lv = *reinterpret_cast<const float4*>(L + row * ld + jrow + l32 * 4);
-            s = lv.x * xv.x + lv.y * xv.y + lv.z * xv.z + lv.w * xv.w;
-        }
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (row < n && l32 == 0) b[row] -= s;
-    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) y[row] = sub ? y[row] - s : s;
 }
 
-// ---- backward: x_j = Linv_jj^T b_j ; b[c] -= sum_r L[jrow + r][c] x_j[r] for columns c < jrow ----
-__global__ __launch_bounds__(256) void k_trsv_bwd_step(const float* __restrict__ L, int64_t ld,
-                                                       const float* __restrict__ dinv_j, int64_t jrow,
-                                                       float* __restrict__ b, float* __restrict__ x) {
-    __shared__ float bj[TB];
-    __shared__ float xj[TB];
-    __shared__ float part[2][TB];
-    const int tid = threadIdx.x;
-    if (tid < TB) bj[tid] = b[jrow + tid];
+// partial[chunk][c] = sum_{r in chunk} A[r][c] x[r];  grid = (ceil(cols/256), rows/128), rows % 128 == 0
+__global__ __launch_bounds__(256) void k_gemv_t_partial_f32(const float* __restrict__ A, int64_t lda, int64_t cols,
+                                                            const float* __restrict__ x, float* __restrict__ partial,
+                                                            int64_t ldp) {
+    __shared__ float xs[128];
+    const int64_t r0 = (int64_t)blockIdx.y * 128;
+    if (threadIdx.x < 128) xs[threadIdx.x] = x[r0 + threadIdx.x];
     __syncthreads();
-    {
-        // x_j[c] = sum_r dinv[r][c] b_j[r]; thread (c, half) sums 64 rows, coalesced over c
-        const int c = tid & 127, half = tid >> 7;
-        float s = 0.0f;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) s = fmaf(dinv_j[(half * 64 + r) * TB + c], bj[half * 64 + r], s);
-        part[half][c] = s;
-    }
-    __syncthreads();
-    if (tid < TB) xj[tid] = part[0][tid] + part[1][tid];
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid < TB) x[jrow + tid] = xj[tid];
-        return;
-    }
-    const int64_t c = (int64_t)(blockIdx.x - 1) * 256 + tid;
-    if (c >= jrow) return;
-    const float* lp = L + jrow * ld + c;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const float* ap = A + r0 * lda + c;
     float s = 0.0f;
-#pragma unroll 8
-    for (int r = 0; r < TB; ++r) s = fmaf(lp[(int64_t)r * ld], xj[r], s);
-    b[c] -= s;
+#pragma unroll 16
+    for (int r = 0; r < 128; ++r) s = fmaf(ap[(int64_t)r * lda], xs[r], s);
+    partial[(int64_t)blockIdx.y * ldp + c] = s;
+}
+
+// y[c] -= sum_chunk partial[chunk][c]  (fixed summation order: results are run-to-run reproducible)
+__global__ __launch_bounds__(256) void k_sub_partials_f32(float* __restrict__ y, const float* __restrict__ partial,
+                                                          int64_t ldp, int nchunk, int64_t cols) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int k = 0; k < nchunk; ++k) s += partial[(int64_t)k * ldp + c];
+    y[c] -= s;
+}
+
+// blocks of `count` identity matrices (bs x bs, ld = bs)
+__global__ __launch_bounds__(256) void k_set_identity_blocks(float* __restrict__ t, int64_t bs, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t e = i % (bs * bs);
+    t[i] = (e / bs == e % bs) ? 1.0f : 0.0f;
+}
+
+// dst_J = src_J^T for `count` blocks of bs x bs (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_blocks(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int64_t bs) {
+    __shared__ float tile[32][33];
+    const int64_t base = (int64_t)blockIdx.z * bs * bs;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = src[base + (r0 + ty + 8 * k) * bs + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[base + (c0 + ty + 8 * k) * bs + r0 + tx] = tile[tx][ty + 8 * k];
 }
 
 // ---- float64 GEMV: y[i*incy] = sum_j A[i][j] x[j*incx] + diag_add * x[i*incx] ----
@@ -178,25 +164,75 @@ inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-// Solves L x = b.  b (length np, float32) is destroyed; x receives the solution.  n = np (padded size).
-int trsv_forward_f32(const float* l, int64_t ld, const float* dinv, int64_t n, float* b, float* x, hipStream_t s) {
-    const int64_t nb = n / TB;
-    for (int64_t j = 0; j < nb; ++j) {
-        const int64_t below = n - (j + 1) * TB;
-        const unsigned grid = 1u + (unsigned)((below + 255) / 256);
-        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(grid), dim3(256), 0, s, l, ld, dinv + j * TB * TB, j * TB, n, b, x);
+// B_J <- B_J L_JJ^-T for `batch` diagonal blocks at once (same recursion as trsm_rlt_f32, batched strides).
+static int trsm_rlt_batched(float* b, int64_t ldb, int64_t sb, int64_t m, const float* l, int64_t ldl, int64_t sl,
+                            const float* dinv, int64_t sd, int64_t n, int batch, hipStream_t s) {
+    if (n == TB)
+        return launch_gemm_nt_f32_batched(b, ldb, b, ldb, dinv, TB, m, TB, TB, 1.0f, 0.0f, false, batch, sb, sb, sd, s);
+    const int64_t n1 = (n / TB / 2) * TB, n2 = n - n1;
+    NNGP_TRY(trsm_rlt_batched(b, ldb, sb, m, l, ldl, sl, dinv, sd, n1, batch, s));
+    NNGP_TRY(launch_gemm_nt_f32_batched(b + n1, ldb, b, ldb, l + n1 * ldl, ldl, m, n2, n1, -1.0f, 1.0f, false, batch, sb,
+                                        sb, sl, s));
+    return trsm_rlt_batched(b + n1, ldb, sb, m, l + n1 * ldl + n1, ldl, sl, dinv + (n1 / TB) * TB * TB, sd, n2, batch, s);
+}
+
+int64_t triinv_block(int64_t np) { return np < 1024 ? np : 1024; }
+
+// Inverts the diagonal blocks (size bs, tail np % bs) of the float32 factor: T_J = L_JJ^-T by a batched
+// triangular solve against the identity (MFMA GEMMs), X_J = T_J^T.  Used by the blocked TRSVs below.
+int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, hipStream_t s) {
+    const int64_t bs = ti.bs;
+    NNGP_REQUIRE(bs % TB == 0 && bs > 0 && np % TB == 0, "triinv_build: bad block size");
+    const int64_t nfull = np / bs, tail = np % bs;
+    const int64_t total = (nfull + (tail ? 1 : 0)) * bs * bs;
+    hipLaunchKernelGGL(k_set_identity_blocks, dim3(blocks256(total)), dim3(256), 0, s, ti.tinv, bs, total);
+    if (nfull > 0)
+        NNGP_TRY(trsm_rlt_batched(ti.tinv, bs, bs * bs, bs, l, ld, bs * (ld + 1), dinv, (bs / TB) * TB * TB, bs,
+                                  (int)nfull, s));
+    if (tail > 0) {
+        const int64_t o = nfull * bs;
+        NNGP_TRY(trsm_rlt_f32(ti.tinv + nfull * bs * bs, bs, tail, l + o * (ld + 1), ld, dinv + (o / TB) * TB * TB, tail, s));
+    }
+    hipLaunchKernelGGL(k_transpose_blocks, dim3((unsigned)(bs / 32), (unsigned)(bs / 32), (unsigned)(nfull + (tail ? 1 : 0))),
+                       dim3(256), 0, s, ti.tinv, ti.xinv, bs);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Solves L x = b in place (b, length np, float32).  Block J: x_J = X_J b_J, then b[below] -= L[below, J] x_J.
+int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s) {
+    const int64_t bs = ti.bs;
+    for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
+        const int64_t sz = (np - o < bs) ? np - o : bs;
+        hipLaunchKernelGGL(k_gemv_n_f32, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, s, ti.xinv + j * bs * bs, bs, sz, sz,
+                           b + o, ti.tmp, 0);
+        NNGP_HIP_CHECK(hipMemcpyAsync(b + o, ti.tmp, sizeof(float) * sz, hipMemcpyDeviceToDevice, s));
+        const int64_t below = np - o - sz;
+        if (below > 0)
+            hipLaunchKernelGGL(k_gemv_n_f32, dim3((unsigned)((below + 3) / 4)), dim3(256), 0, s, l + (o + sz) * ld + o, ld,
+                               below, sz, b + o, b + o + sz, 1);
     }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// Solves L^T x = b.
-int trsv_backward_f32(const float* l, int64_t ld, const float* dinv, int64_t n, float* b, float* x, hipStream_t s) {
-    const int64_t nb = n / TB;
-    for (int64_t j = nb - 1; j >= 0; --j) {
-        const int64_t left = j * TB;
-        const unsigned grid = 1u + (unsigned)((left + 255) / 256);
-        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(grid), dim3(256), 0, s, l, ld, dinv + j * TB * TB, j * TB, b, x);
+// Solves L^T x = b in place.  Block J (last to first): x_J = X_J^T b_J = T_J b_J, then b[:o] -= L[J rows, :o]^T x_J.
+int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s) {
+    const int64_t bs = ti.bs;
+    const int64_t nblk = (np + bs - 1) / bs;
+    for (int64_t j = nblk - 1; j >= 0; --j) {
+        const int64_t o = j * bs;
+        const int64_t sz = (np - o < bs) ? np - o : bs;
+        hipLaunchKernelGGL(k_gemv_n_f32, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, s, ti.tinv + j * bs * bs, bs, sz, sz,
+                           b + o, ti.tmp, 0);
+        NNGP_HIP_CHECK(hipMemcpyAsync(b + o, ti.tmp, sizeof(float) * sz, hipMemcpyDeviceToDevice, s));
+        if (o > 0) {
+            const int nchunk = (int)(sz / 128);
+            hipLaunchKernelGGL(k_gemv_t_partial_f32, dim3((unsigned)((o + 255) / 256), (unsigned)nchunk), dim3(256), 0, s,
+                               l + o * ld, ld, o, b + o, ti.partial, np);
+            hipLaunchKernelGGL(k_sub_partials_f32, dim3((unsigned)((o + 255) / 256)), dim3(256), 0, s, b, ti.partial, np,
+                               nchunk, o);
+        }
     }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -213,13 +249,13 @@ int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, co
 
 // Preconditioned CG for (K + reg I) x = b in float64; M^-1 = (L L^T)^-1 with the float32 factor.
 int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
-              const float* dinv, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
+              const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
               double tol, int* iters_out, double* relres_out, hipStream_t s) {
     auto precond = [&](const double* rin, double* zout) -> int {
         hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks256(np)), dim3(256), 0, s, rin, w.f32a, n, np);
-        NNGP_TRY(trsv_forward_f32(l32, ld32, dinv, np, w.f32a, w.f32b, s));
-        NNGP_TRY(trsv_backward_f32(l32, ld32, dinv, np, w.f32b, w.f32c, s));
-        hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32c, zout, n);
+        NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, s));
+        NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32a, s));
+        hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32a, zout, n);
         return 0;
     };
     // x = 0, r = b

@@ -14,6 +14,7 @@ timeout -k 10 300 python bench.py --config cfg2 --steps 3 --warmup 1 --no-cpu-ba
 cat gpurun_out/bench_cfg2_$TAG.json
 timeout -k 10 600 python bench.py --config cfg3 --steps 3 --warmup 1 > gpurun_out/bench_cfg3_$TAG.json 2> gpurun_out/bench_cfg3_$TAG.err || { echo "bench cfg3 failed"; tail -5 gpurun_out/bench_cfg3_$TAG.err; }
 cat gpurun_out/bench_cfg3_$TAG.json
+timeout -k 10 300 python scripts/microbench.py > gpurun_out/microbench_$TAG.json 2> gpurun_out/microbench_$TAG.err; cat gpurun_out/microbench_$TAG.json | tr -d "\n" | cut -c1-3000; echo
 cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o cfg3 -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG.log 2>&1
 echo "rocprof exit=$?"
 cd $GRAFT_REPO_ROOT && find gpurun_out/prof_$TAG -name "*stats*" | head; find gpurun_out/prof_$TAG -name "*kernel_stats*" -exec head -25 {} \;

@@ -131,7 +131,7 @@ def test_gemm_is_a_k_ordered_fp32_fma_chain():
         pytest.fail("GEMM is not bit-identical to the emulated fma chain (max diff %g)" % d0)
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 128), (384, 256, 512), (1024, 1024, 2048)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 128), (384, 256, 512), (1024, 1024, 2048), (2048, 2048, 256), (1536, 1024, 128)])
 def test_gemm_random(m, n, k):
     torch.manual_seed(1)
     a = torch.randn((m, k), device=G.dev()); b = torch.randn((n, k), device=G.dev()); c0 = torch.randn((m, n), device=G.dev())
@@ -152,9 +152,10 @@ def test_gemm_random(m, n, k):
     assert torch.all(c[~tile_lower] == 0)  # tiles above the diagonal are never touched
 
 
-def test_gemm_in_place_inverse_block():
+@pytest.mark.parametrize("rows", [128, 512, 24576 + 128])  # 64x128 and 128x128 workgroup tiles
+def test_gemm_in_place_inverse_block(rows):
     torch.manual_seed(2)
-    bmat = torch.randn((512, 128), device=G.dev()); inv = torch.randn((128, 128), device=G.dev())
+    bmat = torch.randn((rows, 128), device=G.dev()); inv = torch.randn((128, 128), device=G.dev())
     ref = bmat.double() @ inv.double().T
     G.gemm_nt(bmat, bmat, inv, 1.0, 0.0)
     assert (bmat.double() - ref).abs().max().item() < 1e-4
@@ -167,7 +168,7 @@ def _spd(n, seed, cond_reg=1e-3):
     return K + cond_reg * np.trace(K) / n * np.eye(n)
 
 
-@pytest.mark.parametrize("n", [128, 256, 640, 2048])
+@pytest.mark.parametrize("n", [128, 256, 640, 2048, 5120])
 def test_potrf_against_lapack(n):
     A = _spd(n, n)
     a = torch.from_numpy(np.tril(A).astype(np.float32)).to(G.dev())
