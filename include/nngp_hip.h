@@ -113,6 +113,11 @@ int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
 int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode,
                        double* mean, double* var_or_cov, void* stream);
 
+/* Float64 refinement of the posterior covariance: `sweeps` residual-correction sweeps (each one [mt, N] x [N, N]
+ * float64 MFMA product) before the second-order variance formula.  Default 1; 0 = float32 triangular solve only
+ * (fast, variances accurate to ~cond * eps32 of the PRIOR variance).  Means are float64-accurate either way. */
+int nngp_model_set_refine(nngp_model* m, int32_t sweeps);
+
 /* ---- building blocks exported for parity tests and the integration notes ----------------------
  * Blocked lower Cholesky of a float32 matrix in place (n multiple of 128, ld >= n).  dinv: workspace of
  * (n/128) * 128*128 floats receiving the inverses of the diagonal blocks.  clamped: device int32.   */
@@ -121,6 +126,10 @@ int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clampe
  * lower_only != 0: only tiles on or below the diagonal are touched (SYRK-style, M == N).            */
 int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
                      int64_t m, int64_t n, int64_t k, float alpha, float beta, int32_t lower_only,
+                     void* stream);
+/* C[M,N] = beta*Cin + alpha * A[M,K] B[N,K]^T on float64 MFMA (M, N multiples of 128, K of 16; Cin may be C). */
+int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                     const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                      void* stream);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,

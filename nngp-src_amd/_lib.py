@@ -23,7 +23,8 @@ ABI_SYMBOLS = (
     "nngp_version", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
-    "nngp_model_alpha", "nngp_model_predict", "nngp_potrf_f32", "nngp_gemm_nt_f32", "nngp_trsm_rlt_f32",
+    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
+    "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32",
 )
 
 
@@ -72,6 +73,8 @@ def load():
     lib.nngp_model_info.argtypes = [vp, ctypes.POINTER(NngpFitInfo)]
     lib.nngp_model_alpha.argtypes = [vp, vp, vp]
     lib.nngp_model_predict.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.nngp_model_set_refine.argtypes = [vp, i32]
+    lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.nngp_gemm_nt_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float, i32, vp]
     lib.nngp_trsm_rlt_f32.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp]

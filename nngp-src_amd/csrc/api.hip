@@ -84,6 +84,21 @@ struct nngp_model {
     double* ktt64 = nullptr;     // [full_cap, full_cap]
     float* vvt32 = nullptr;      // [fullp, fullp]
 
+    // float64 refinement of the posterior covariance (grown on demand)
+    int var_refine = 1;          // correction sweeps before the second-order variance formula (0 = float32 only)
+    float* lt32 = nullptr;       // [np_cap, np_cap] L^T, built lazily after a fit
+    float* dinvt = nullptr;      // transposed inverted 128-blocks
+    bool lt_ready = false;
+    int64_t refine_cap = 0;      // padded row capacity of z64 / r64
+    double* z64 = nullptr;       // [refine_cap, np_cap]  Z ~ K_td (K + reg I)^-1
+    double* r64 = nullptr;       // [refine_cap, np_cap]  residual / product workspace
+    double* covp64 = nullptr;    // [fullp, fullp] padded covariance
+    // NTK covariance needs the NNGP kernels as well
+    double* kaux64 = nullptr;    // [np_cap, np_cap] NNGP train-train kernel when get == ntk
+    bool aux_ready = false;
+    double* ktd_aux = nullptr;   // [ktd rows, np_cap] NNGP cross kernel when get == ntk
+    int64_t ktd_aux_cap = 0;
+
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
     int iters = 0;
 
@@ -95,6 +110,7 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(ktt64); dev_free(vvt32);
+        dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
 };
 
@@ -128,7 +144,7 @@ int ensure_predict_capacity(nngp_model* m, int64_t mt, bool need_ktd) {
         const int64_t cap = mt > m->m_cap ? mt : m->m_cap;
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         dev_free(m->ktd64);
-        NNGP_TRY(dev_alloc(&m->ktd64, cap * m->np_cap));
+        NNGP_TRY(dev_alloc(&m->ktd64, round_up(cap, TB) * m->np_cap));
         m->ktd_cap = cap;
     }
     return 0;
@@ -139,11 +155,74 @@ int ensure_full_cov_capacity(nngp_model* m, int64_t mt) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         dev_free(m->ktt64); dev_free(m->vvt32);
         const int64_t mp = round_up(mt, TB);
-        NNGP_TRY(dev_alloc(&m->ktt64, mt * mp));
+        dev_free(m->covp64);
+        NNGP_TRY(dev_alloc(&m->ktt64, mp * mp));
         NNGP_TRY(dev_alloc(&m->vvt32, mp * mp));
+        NNGP_TRY(dev_alloc(&m->covp64, mp * mp));
         m->full_cap = mt;
     }
     return 0;
+}
+
+int ensure_refine_capacity(nngp_model* m, int64_t mp) {
+    if (mp > m->refine_cap) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(m->z64); dev_free(m->r64);
+        NNGP_TRY(dev_alloc(&m->z64, mp * m->np_cap));
+        NNGP_TRY(dev_alloc(&m->r64, mp * m->np_cap));
+        m->refine_cap = mp;
+    }
+    return 0;
+}
+
+// L^T and the transposed inverted diagonal blocks: operands of the "B L^-1" half of (L L^T)^-1.
+int ensure_lt(nngp_model* m, hipStream_t s) {
+    if (m->lt_ready) return 0;
+    if (m->lt32 == nullptr) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        NNGP_TRY(dev_alloc(&m->lt32, m->np_cap * m->np_cap));
+        NNGP_TRY(dev_alloc(&m->dinvt, (m->np_cap / TB) * TB * TB));
+    }
+    NNGP_TRY(launch_transpose_f32(m->a32, m->np, m->lt32, m->np, m->np, s));
+    NNGP_TRY(launch_transpose_blocks_f32(m->dinv, m->dinvt, TB, m->np / TB, s));
+    m->lt_ready = true;
+    return 0;
+}
+
+// b32 [mp, np] <- b32 (L L^T)^-1   (rows are right-hand sides)
+int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    NNGP_TRY(trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->np, m->dinv, m->np, s));
+    return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+}
+
+// z64 <- rows of `rhs` [mp, np] times (K + reg I)^-1, float32 solves corrected by `sweeps` float64 residual sweeps.
+// On return r64 holds the residual rhs - z64 (K + reg I) of the returned z64.
+int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps, hipStream_t s) {
+    const int64_t np = m->np;
+    NNGP_TRY(launch_convert_f64_f32(rhs, np, m->b32, np, mp, np, mp, np, s));
+    NNGP_TRY(apply_inverse_f32(m, mp, s));
+    NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));
+    for (int it = 0;; ++it) {
+        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, rhs, np, m->z64, np, m->k64, np, mp, np, np, -1.0, 1.0, s));
+        NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+        if (it == sweeps) break;
+        NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
+        NNGP_TRY(apply_inverse_f32(m, mp, s));
+        NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, true, s));
+    }
+    return 0;
+}
+
+int build_cross(nngp_model* m, const double* xt, const double* qt, int64_t mt, int64_t mp, bool nngp, double* out,
+                hipStream_t s) {
+    NNGP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * mp * m->np, s));
+    BuildArgs a{};
+    a.x1 = xt; a.x2 = m->x; a.q1 = qt; a.q2 = m->q;
+    a.n1 = mt; a.n2 = m->n; a.d = m->d;
+    a.row_begin = 0; a.row_end = mt; a.sym = 0;
+    a.ld64 = a.ld32 = m->np;
+    if (nngp) a.nngp64 = out; else a.ntk64 = out;
+    return launch_kernel_build(a, m->arch, s);
 }
 
 }  // namespace
@@ -301,6 +380,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     a.ld64 = a.ld32 = m->np;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
     NNGP_TRY(launch_kernel_build(a, m->arch, s));
+    NNGP_TRY(launch_zero_pad_f64(m->k64, m->np, m->n, m->np, s));  // float64 GEMMs read the padded matrix
     m->built = true;  // the caller vouches for the remaining rows (all-gather) before factor
     m->factored = m->solved = false;
     return 0;
@@ -317,6 +397,8 @@ int nngp_model_factor(nngp_model* m, void* stream) {
     NNGP_TRY(triinv_build(m->a32, m->np, m->dinv, m->np, m->tri, s));
     m->factored = true;
     m->solved = false;
+    m->lt_ready = false;
+    m->aux_ready = false;
     return 0;
 }
 
@@ -376,60 +458,112 @@ int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream) {
     return 0;
 }
 
+int nngp_model_set_refine(nngp_model* m, int32_t sweeps) {
+    NNGP_REQUIRE(m != nullptr && sweeps >= 0 && sweeps <= 8, "set_refine: sweeps must be in [0, 8]");
+    m->var_refine = sweeps;
+    return 0;
+}
+
 int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode, double* mean,
                        double* var_or_cov, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->solved, "predict: fit the model first");
     NNGP_REQUIRE(cov_mode >= NNGP_COV_NONE && cov_mode <= NNGP_COV_FULL, "predict: bad cov_mode");
     NNGP_REQUIRE(mean != nullptr && (cov_mode == NNGP_COV_NONE || var_or_cov != nullptr), "predict: NULL output");
-    NNGP_REQUIRE(cov_mode == NNGP_COV_NONE || m->get == NNGP_GET_NNGP,
-                 "predict: the NTK posterior covariance is not implemented yet (mean only)");
     const bool on_train = (x_test == nullptr);
     if (on_train) mt = m->n;
     NNGP_REQUIRE(mt >= 0, "predict: negative row count");
     if (mt == 0) return 0;
+    const bool is_ntk = (m->get == NNGP_GET_NTK);
     const int64_t n = m->n, np = m->np, mp = round_up(mt, TB);
     NNGP_TRY(ensure_predict_capacity(m, mt, !on_train));
 
+    // ---- cross kernel of `get` and the mean: mu = K_td alpha (float64) ----
     const double* xt = on_train ? m->x : x_test;
-    const double* ktd = m->k64;  // x_test=None: K_td = K_dd (estimator.py:37-40)
+    const double* ktd = m->k64;  // x_test=None: K_td = K_dd (estimator.py:37-40); its padding is zero
     const double* qt = m->q;
     if (!on_train) {
         NNGP_TRY(launch_row_sqnorm(xt, mt, m->d, m->xt_q, s));
         qt = m->xt_q;
-        BuildArgs a{};
-        a.x1 = xt; a.x2 = m->x; a.q1 = m->xt_q; a.q2 = m->q;
-        a.n1 = mt; a.n2 = n; a.d = m->d;
-        a.row_begin = 0; a.row_end = mt; a.sym = 0;
-        a.ld64 = a.ld32 = np;
-        if (m->get == NNGP_GET_NNGP) a.nngp64 = m->ktd64; else a.ntk64 = m->ktd64;
-        NNGP_TRY(launch_kernel_build(a, m->arch, s));
+        NNGP_TRY(build_cross(m, xt, qt, mt, mp, !is_ntk, m->ktd64, s));
         ktd = m->ktd64;
     }
     for (int c = 0; c < m->ny; ++c)
         NNGP_TRY(launch_gemv_f64(ktd, np, mt, n, m->alpha + c, m->ny, mean + c, m->ny, 0.0, s));
     if (cov_mode == NNGP_COV_NONE) return 0;
-
-    // V^T = K_td L^-T  (float32 MFMA triangular solve with mt right-hand sides)
-    NNGP_TRY(launch_convert_f64_f32(ktd, np, m->b32, np, mt, n, mp, np, s));
-    NNGP_TRY(trsm_rlt_f32(m->b32, np, mp, m->a32, np, m->dinv, np, s));
-    if (cov_mode == NNGP_COV_DIAG) {
-        NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));
-        return launch_row_sqsum_f32(m->b32, np, mt, np, m->tt_diag, var_or_cov, s);
-    }
-    // full covariance: K_tt - V^T V
-    NNGP_TRY(ensure_full_cov_capacity(m, mt));
-    {
+    const bool full = (cov_mode == NNGP_COV_FULL);
+    if (full) NNGP_TRY(ensure_full_cov_capacity(m, mt));
+    NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));  // NNGP K(x_t, x_t)
+    auto build_ktt = [&]() -> int {  // NNGP K_tt [mt, mt] into ktt64 (ld = mp)
         BuildArgs a{};
         a.x1 = xt; a.x2 = xt; a.q1 = qt; a.q2 = qt;
         a.n1 = mt; a.n2 = mt; a.d = m->d;
         a.row_begin = 0; a.row_end = mt; a.sym = 1;
         a.ld64 = a.ld32 = mp;
         a.nngp64 = m->ktt64;
-        NNGP_TRY(launch_kernel_build(a, m->arch, s));
+        return launch_kernel_build(a, m->arch, s);
+    };
+
+    if (!is_ntk && m->var_refine == 0) {
+        // float32 only: V^T = K_td L^-T, cov = K_tt - V^T V  (fast; error ~ cond * eps32 relative to the prior)
+        NNGP_TRY(launch_convert_f64_f32(ktd, np, m->b32, np, mp, np, mp, np, s));
+        NNGP_TRY(trsm_rlt_f32(m->b32, np, mp, m->a32, np, m->dinv, np, s));
+        if (!full) return launch_row_sqsum_f32(m->b32, np, mt, np, m->tt_diag, var_or_cov, s);
+        NNGP_TRY(build_ktt());
+        NNGP_TRY(launch_gemm_nt_f32(m->vvt32, mp, m->b32, np, m->b32, np, mp, mp, np, 1.0f, 0.0f, false, s));
+        return launch_cov_finish(m->ktt64, mp, m->vvt32, mp, mt, var_or_cov, s);
     }
-    NNGP_TRY(launch_gemm_nt_f32(m->vvt32, mp, m->b32, np, m->b32, np, mp, mp, np, 1.0f, 0.0f, false, s));
-    return launch_cov_finish(m->ktt64, mp, m->vvt32, mp, mt, var_or_cov, s);
+
+    NNGP_TRY(ensure_lt(m, s));
+    NNGP_TRY(ensure_refine_capacity(m, mp));
+    if (!is_ntk) {
+        // NNGP: cov_ij = K_tt,ij - k_i^T A^-1 k_j.  With Z ~ K_td A^-1 and R = K_td - Z A (float64),
+        //   k_i^T A^-1 k_j = z_i . (k_j + r_j) + O(|error|^2): the first-order error of Z cancels.
+        NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine, s));
+        if (!full) return launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s);
+        NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, 1.0, np, mp, np, s));  // G = K_td + R
+        NNGP_TRY(build_ktt());
+        NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->z64, np, m->r64, np, mp, mp, np, -1.0, 1.0, s));
+        return launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s);
+    }
+
+    // NTK (train.py --kernel_type ntk): with Z = Theta_td (Theta_dd + reg I)^-1,
+    //   cov = K_tt + Z K_dd Z^T - (K_td Z^T + h.c.),  K = NNGP kernels.
+    if (!m->aux_ready) {
+        if (m->kaux64 == nullptr) {
+            NNGP_HIP_CHECK(hipDeviceSynchronize());
+            NNGP_TRY(dev_alloc(&m->kaux64, m->np_cap * m->np_cap));
+        }
+        BuildArgs a{};
+        a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
+        a.n1 = n; a.n2 = n; a.d = m->d;
+        a.row_begin = 0; a.row_end = n; a.sym = 1;
+        a.ld64 = a.ld32 = np;
+        a.nngp64 = m->kaux64;
+        NNGP_TRY(launch_kernel_build(a, m->arch, s));
+        NNGP_TRY(launch_zero_pad_f64(m->kaux64, np, n, np, s));
+        m->aux_ready = true;
+    }
+    const double* ktd_n = m->kaux64;  // NNGP cross kernel; x_test=None: K_dd itself
+    if (!on_train) {
+        if (mp > m->ktd_aux_cap) {
+            NNGP_HIP_CHECK(hipDeviceSynchronize());
+            dev_free(m->ktd_aux);
+            NNGP_TRY(dev_alloc(&m->ktd_aux, mp * m->np_cap));
+            m->ktd_aux_cap = mp;
+        }
+        NNGP_TRY(build_cross(m, xt, qt, mt, mp, true, m->ktd_aux, s));
+        ktd_n = m->ktd_aux;
+    }
+    NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine + 1, s));  // no error cancellation here: one more sweep
+    NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd
+    if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
+        return launch_rowdot_f64(m->z64, ktd_n, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);
+    NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd_n, -1.0, np, mp, np, s));  // G = W - K_td
+    NNGP_TRY(build_ktt());
+    NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->r64, np, m->z64, np, mp, mp, np, 1.0, 1.0, s));
+    NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->covp64, mp, m->z64, np, ktd_n, np, mp, mp, np, -1.0, 1.0, s));
+    return launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s);
 }
 
 int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream) {
@@ -442,6 +576,13 @@ int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const f
                      int64_t n, int64_t k, float alpha, float beta, int32_t lower_only, void* stream) {
     NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr, "gemm_nt_f32: NULL argument");
     return launch_gemm_nt_f32(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only != 0, (hipStream_t)stream);
+}
+
+int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                     const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                     void* stream) {
+    NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr, "gemm_nt_f64: NULL argument");
+    return launch_gemm_nt_f64(c, ldc, cin, ldcin, a, lda, b, ldb, m, n, k, alpha, beta, (hipStream_t)stream);
 }
 
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,

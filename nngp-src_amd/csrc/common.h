@@ -84,7 +84,16 @@ int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, fl
 int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
                  hipStream_t s);
 
+int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
+                 hipStream_t s);
+
+// ---- gemm_f64.hip ----
+int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                       const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                       hipStream_t s);
+
 // ---- solve.hip ----
+int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_t count, hipStream_t s);
 // Inverted diagonal blocks (size bs) of the float32 factor for the blocked triangular solves.
 struct TriInv {
     int64_t bs = 0;
@@ -119,6 +128,15 @@ int launch_row_sqsum_f32(const float* v, int64_t ld, int64_t rows, int64_t cols,
                          double* out, hipStream_t s);
 int launch_cov_finish(const double* ktt, int64_t ldk, const float* vvt, int64_t ldv, int64_t m, double* cov,
                       hipStream_t s);
+int launch_zero_pad_f64(double* a, int64_t ld, int64_t n, int64_t np, hipStream_t s);
+int launch_f32_to_f64_mat(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
+                          bool accumulate, hipStream_t s);
+int launch_axpby_mat(double* r, double a, const double* k, double b, int64_t ld, int64_t rows, int64_t cols,
+                     hipStream_t s);
+int launch_rowdot_f64(const double* z, const double* k, double kscale, const double* r, int64_t ld, int64_t rows,
+                      int64_t cols, const double* base, double sign, double* out, hipStream_t s);
+int launch_copy_mat_f64(const double* src, int64_t lds, double* dst, int64_t m, hipStream_t s);
+int launch_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t n, hipStream_t s);
 int launch_strided_copy_f64(const double* src, int64_t incs, double* dst, int64_t incd, int64_t n, hipStream_t s);
 
 }  // namespace nngp

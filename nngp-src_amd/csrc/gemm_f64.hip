@@ -1,0 +1,137 @@
+// float64 "NT" GEMM on the gfx950 matrix cores:  C[M,N] = beta*Cin + alpha * A[M,K] * B[N,K]^T.
+//
+// Used by the float64 refinement of the posterior covariance (a4, reference train.py:157-158): the
+// residual R = K_td - Z (K_dd + reg I) is an [M, N] x [N, N] product that must be float64 because the
+// float32 Cholesky factor only approximates (K + reg I)^-1 to ~cond * eps32.  K_dd is
+// symmetric, so its rows serve as the K-contiguous "B" operand and no transposed copy is needed.
+//
+// Same skeleton as gemm_f32.hip: 128x128 tile, 4 waves (2x2), 64x64 per wave = 4x4 accumulators of
+// v_mfma_f64_16x16x4_f64 (128 VGPRs), BK = 16 doubles (128-byte LDS rows, same XOR swizzle), double-buffered
+// register staging.  Lane l holds A[i = l & 15][k = l >> 4]; a 16-byte LDS read gives it two consecutive k,
+// used by two MFMAs.  C/D layout of the f64 MFMA: col = l & 15, row = (l >> 4) + 4 * reg  (it differs from
+// the f32 shapes -- cdna_hip_programming.md section 3).
+#include "common.h"
+
+namespace nngp {
+
+namespace {
+
+constexpr int DBM = 128, DBN = 128, DBK = 16;
+constexpr int DSTAGE = (DBM + DBN) * DBK;  // doubles per stage (32 KiB)
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int lds_off64(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, const double* Cin, int64_t ldcin,
+                                                        const double* A, int64_t lda, const double* B, int64_t ldb,
+                                                        int tiles_n, int nk, double alpha, double beta) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * DSTAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bi = blockIdx.x / tiles_n, bj = blockIdx.x % tiles_n;
+    const double* Ab = A + (int64_t)bi * DBM * lda;
+    const double* Bb = B + (int64_t)bj * DBN * ldb;
+
+    f64x2 ga[4], gb[4];
+    const int ld_row = tid >> 3, ld_ch = tid & 7;
+    auto load_tile = [&](int t) {
+        const int64_t k0 = (int64_t)t * DBK + ld_ch * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ga[e] = *reinterpret_cast<const f64x2*>(Ab + (int64_t)(ld_row + 32 * e) * lda + k0);
+            gb[e] = *reinterpret_cast<const f64x2*>(Bb + (int64_t)(ld_row + 32 * e) * ldb + k0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sa_ = reinterpret_cast<char*>(smem + buf * DSTAGE);
+        char* sb_ = sa_ + DBM * DBK * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<f64x2*>(sa_ + lds_off64(ld_row + 32 * e, ld_ch)) = ga[e];
+            *reinterpret_cast<f64x2*>(sb_ + lds_off64(ld_row + 32 * e, ld_ch)) = gb[e];
+        }
+    };
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+    const int r16 = lane & 15, g = lane >> 4;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) load_tile(t + 1);
+        const char* sa_ = reinterpret_cast<const char*>(smem + (t & 1) * DSTAGE);
+        const char* sb_ = sa_ + DBM * DBK * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f64x2 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const f64x2*>(sa_ + lds_off64(wm * 64 + i * 16 + r16, 4 * s + g));
+                fb[i] = *reinterpret_cast<const f64x2*>(sb_ + lds_off64(wn * 64 + i * 16 + r16, 4 * s + g));
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    const int64_t row_base = (int64_t)bi * DBM + wm * 64;
+    const int64_t col_base = (int64_t)bj * DBN + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row0 = row_base + i * 16 + g, col = col_base + j * 16 + r16;
+            double cin[4];
+            if (beta != 0.0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cin[r] = Cin[(row0 + 4 * r) * ldcin + col];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v = fma(beta, cin[r], v);
+                C[(row0 + 4 * r) * ldc + col] = v;
+            }
+        }
+}
+
+}  // namespace
+
+int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                       const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                       hipStream_t s) {
+    if (m <= 0 || n <= 0) return 0;
+    NNGP_REQUIRE(m % DBM == 0 && n % DBN == 0 && k % DBK == 0 && k > 0,
+                 "gemm_nt_f64: m, n must be multiples of 128 and k of 16 (m=%lld n=%lld k=%lld)", (long long)m,
+                 (long long)n, (long long)k);
+    NNGP_REQUIRE(lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0,
+                 "gemm_nt_f64: operands must be 16-byte aligned");
+    NNGP_REQUIRE(lda >= k && ldb >= k && ldc >= n && (beta == 0.0 || (cin != nullptr && ldcin >= n)),
+                 "gemm_nt_f64: leading dimension too small");
+    const int64_t tm = m / DBM, tn = n / DBN;
+    NNGP_REQUIRE(tm * tn < 2147483647LL, "gemm_nt_f64: grid too large");
+    hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
+                       a, lda, b, ldb, (int)tn, (int)(k / DBK), alpha, beta);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace nngp

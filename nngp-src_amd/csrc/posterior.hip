@@ -80,6 +80,82 @@ __global__ void k_strided_copy(const double* src, int64_t incs, double* dst, int
     if (i < n) dst[i * incd] = src[i * incs];
 }
 
+// zero the padding of an [np, np] float64 matrix whose valid part is [n, n]
+__global__ __launch_bounds__(256) void k_zero_pad_f64(double* __restrict__ a, int64_t ld, int64_t n, int64_t np,
+                                                      int64_t row0) {
+    const int64_t row = row0 + blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row < n) {
+        if (c < np - n) a[row * ld + n + c] = 0.0;  // columns [n, np) of a valid row
+    } else if (c < np) {
+        a[row * ld + c] = 0.0;                       // a whole padding row
+    }
+}
+
+// dst (f64) = [dst +] float64(src (f32)), [rows, cols]
+__global__ __launch_bounds__(256) void k_f32_to_f64_mat(const float* __restrict__ src, int64_t lds, double* __restrict__ dst,
+                                                        int64_t ldd, int64_t cols, int accumulate) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (c >= cols) return;
+    const float2 v = *reinterpret_cast<const float2*>(src + row * lds + c);
+    double2* d = reinterpret_cast<double2*>(dst + row * ldd + c);
+    double2 o = accumulate ? *d : make_double2(0.0, 0.0);
+    o.x += (double)v.x;
+    o.y += (double)v.y;
+    *d = o;
+}
+
+// r = a * r + b * k  (elementwise, [rows, cols] with a common leading dimension)
+__global__ __launch_bounds__(256) void k_axpby_mat(double* __restrict__ r, double a, const double* __restrict__ k,
+                                                   double b, int64_t ld, int64_t cols) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    r[row * ld + c] = fma(b, k[row * ld + c], a * r[row * ld + c]);
+}
+
+// out[i] = base[i] + sign * sum_j z[i][j] * (kscale * k[i][j] + r[i][j])   (k or r may be NULL)
+__global__ __launch_bounds__(256) void k_rowdot_f64(const double* __restrict__ z, const double* __restrict__ k,
+                                                    double kscale, const double* __restrict__ r, int64_t ld,
+                                                    int64_t cols, const double* __restrict__ base, double sign,
+                                                    double* __restrict__ out) {
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < cols; j += 256) {
+        double g = 0.0;
+        if (k) g = kscale * k[row * ld + j];
+        if (r) g += r[row * ld + j];
+        s = fma(z[row * ld + j], g, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = base[row] + sign * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// dst[m, m] (dense) = src[m, m] (leading dimension lds)
+__global__ __launch_bounds__(256) void k_copy_mat_f64(const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
+                                                      int64_t m) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < m) dst[row * m + c] = src[row * lds + c];
+}
+
+// dst = src^T for a square float32 matrix (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
+                                                      int64_t ldd) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = src[(r0 + ty + 8 * k) * lds + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[(c0 + ty + 8 * k) * ldd + r0 + tx] = tile[tx][ty + 8 * k];
+}
+
 }  // namespace
 
 int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np, double reg,
@@ -129,6 +205,62 @@ int launch_cov_finish(const double* ktt, int64_t ldk, const float* vvt, int64_t 
 int launch_strided_copy_f64(const double* src, int64_t incs, double* dst, int64_t incd, int64_t n, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_strided_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, incs, dst, incd, n);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_zero_pad_f64(double* a, int64_t ld, int64_t n, int64_t np, hipStream_t s) {
+    if (np == n) return 0;
+    for (int64_t r0 = 0; r0 < np; r0 += 65535) {
+        const int64_t nr = (np - r0 < 65535) ? np - r0 : 65535;
+        hipLaunchKernelGGL(k_zero_pad_f64, dim3((unsigned)((np + 255) / 256), (unsigned)nr), dim3(256), 0, s, a, ld, n, np, r0);
+    }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_f32_to_f64_mat(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
+                          bool accumulate, hipStream_t s) {
+    NNGP_REQUIRE(cols % 2 == 0 && lds % 2 == 0 && ldd % 2 == 0, "f32_to_f64_mat: even widths required");
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = (rows - r0 < 65535) ? rows - r0 : 65535;
+        hipLaunchKernelGGL(k_f32_to_f64_mat, dim3((unsigned)((cols / 2 + 255) / 256), (unsigned)nr), dim3(256), 0, s,
+                           src + r0 * lds, lds, dst + r0 * ldd, ldd, cols, accumulate ? 1 : 0);
+    }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_axpby_mat(double* r, double a, const double* k, double b, int64_t ld, int64_t rows, int64_t cols,
+                     hipStream_t s) {
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = (rows - r0 < 65535) ? rows - r0 : 65535;
+        hipLaunchKernelGGL(k_axpby_mat, dim3((unsigned)((cols + 255) / 256), (unsigned)nr), dim3(256), 0, s, r + r0 * ld, a,
+                           k + r0 * ld, b, ld, cols);
+    }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rowdot_f64(const double* z, const double* k, double kscale, const double* r, int64_t ld, int64_t rows,
+                      int64_t cols, const double* base, double sign, double* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_rowdot_f64, dim3((unsigned)rows), dim3(256), 0, s, z, k, kscale, r, ld, cols, base, sign, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_copy_mat_f64(const double* src, int64_t lds, double* dst, int64_t m, hipStream_t s) {
+    if (m <= 0) return 0;
+    NNGP_REQUIRE(m <= 65535, "copy_mat: at most 65535 rows");
+    hipLaunchKernelGGL(k_copy_mat_f64, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, s, src, lds, dst, m);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t n, hipStream_t s) {
+    NNGP_REQUIRE(n % 32 == 0 && n / 32 <= 65535, "transpose: n must be a multiple of 32");
+    hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, s, src, lds, dst, ldd);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
                                                     float pivot_floor) {
     __shared__ float Ls[128 * LS];
     __shared__ float Xs[128 * LS];
+    __shared__ float colbuf[64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
         for (int e = 0; e < 16; ++e) {
             const int idx = (tid + 256 * e) * 4;
             const int r = idx >> 7, c = idx & 127;
-            v[e] = (c <= r) ? *reinterpret_cast<const float4*>(A + (int64_t)r * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[e] = *reinterpret_cast<const float4*>(A + (int64_t)r * ld + c);  // upper entries are masked below
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
             const int r = idx >> 7, c = idx & 127;
             float* lp = Ls + r * LS + c;
             float* xp = Xs + r * LS + c;
-            lp[0] = v[e].x;
+            lp[0] = (c <= r) ? v[e].x : 0.0f;
             lp[1] = (c + 1 <= r) ? v[e].y : 0.0f;
             lp[2] = (c + 2 <= r) ? v[e].z : 0.0f;
             lp[3] = (c + 3 <= r) ? v[e].w : 0.0f;
@@ -97,41 +98,46 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
         float* Djj = Ls + (jb * 32) * LS + jb * 32;
         float* Xjj = Xs + (jb * 32) * LS + jb * 32;
         if (wave == 0) {
+            // One wave factors and inverts the 32x32 diagonal sub-block.  Lane i owns row i in registers; the
+            // values every lane needs (pivot, column j) travel through a 32-float LDS line read back as
+            // broadcasts -- an LDS round trip per column instead of ~500 v_readlane + hazard nops.
             const int i = lane & 31;
-            float a[32], x[32];
+            float a[32], x[32], invd[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) a[k] = Djj[i * LS + k];
-            // ---- 32x32 Cholesky, lane i owns row i ----
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                float d = readlane_f(a[j], j);
+                float* col = colbuf + (j & 1) * 32;
+                if (lane < 32) col[i] = a[j];  // current column j (rows >= j are valid)
+                float d = col[j];
+                asm volatile("" : "+v"(d));  // keep wave-uniform values in VGPRs (no SGPR spills / readlane traffic)
                 if (!(d > pivot_floor)) {
                     d = pivot_floor > 0.0f ? pivot_floor : 1.0e-30f;
                     ++nclamp;
                 }
-                const float sq = sqrtf(d), inv = 1.0f / sq;
-                a[j] = (i == j) ? sq : a[j] * inv;
+                float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, ~1 ulp: ample for a preconditioner
+                asm volatile("" : "+v"(inv));
+                invd[j] = inv;
+                const float lij = a[j] * inv;                // L[i][j] for i > j
+                a[j] = (i == j) ? d * inv : lij;
 #pragma unroll
-                for (int k = j + 1; k < 32; ++k) {
-                    const float lkj = readlane_f(a[j], k);
-                    a[k] = fmaf(-a[j], lkj, a[k]);
-                }
-            }
-            // ---- inverse of the 32x32 factor, lane c owns column c ----
-#pragma unroll
-            for (int ii = 0; ii < 32; ++ii) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < ii; ++k) s = fmaf(readlane_f(a[k], ii), x[k], s);
-                const float lii = readlane_f(a[ii], ii);
-                x[ii] = (((i == ii) ? 1.0f : 0.0f) - s) / lii;
+                for (int k = j + 1; k < 32; ++k) a[k] = fmaf(-lij, col[k] * inv, a[k]);  // a[i][k] -= L[i][j] L[k][j]
             }
             if (lane < 32) {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    Djj[i * LS + k] = (k <= i) ? a[k] : 0.0f;
-                    Xjj[k * LS + i] = x[k];  // X[k][c = i]
-                }
+                for (int k = 0; k < 32; ++k) Djj[i * LS + k] = (k <= i) ? a[k] : 0.0f;
+            }
+            // inverse: lane c owns column c of X = L^-1;  X[ii][c] = (delta - sum_{k<ii} L[ii][k] X[k][c]) / L[ii][ii]
+#pragma unroll
+            for (int ii = 0; ii < 32; ++ii) {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < ii; ++k) sacc = fmaf(Djj[ii * LS + k], x[k], sacc);  // broadcast LDS reads
+                x[ii] = (((i == ii) ? 1.0f : 0.0f) - sacc) * invd[ii];
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) Xjj[k * LS + i] = x[k];  // X[k][c = i]
             }
         }
         __syncthreads();
@@ -220,6 +226,20 @@ int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, 
     // B2 -= B1 * L21^T,  L21 = L[n1:, :n1]
     NNGP_TRY(launch_gemm_nt_f32(b + n1, ldb, b, ldb, l + n1 * ldl, ldl, m, n2, n1, -1.0f, 1.0f, false, s));
     return trsm_rlt_f32(b + n1, ldb, m, l + n1 * ldl + n1, ldl, dinv + (n1 / TB) * TB * TB, n2, s);
+}
+
+// B[m, n] <- B * U^-T with U = L^T stored explicitly (`lt`, upper triangular, row-major); dinvt holds the
+// TRANSPOSED inverted diagonal blocks.  Together with trsm_rlt_f32 this applies (L L^T)^-1 to the rows of B:
+// Z = (B L^-T) L^-1.  Columns are resolved last-to-first; the update B1 -= X2 U12^T is again an NT GEMM.
+int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
+                 hipStream_t s) {
+    if (m <= 0 || n <= 0) return 0;
+    if (n == TB) return launch_gemm_nt_f32(b, ldb, b, ldb, dinvt, TB, m, TB, TB, 1.0f, 0.0f, false, s);
+    const int64_t n1 = (n / TB / 2) * TB, n2 = n - n1;
+    NNGP_TRY(trsm_rut_f32(b + n1, ldb, m, lt + n1 * ldl + n1, ldl, dinvt + (n1 / TB) * TB * TB, n2, s));
+    // B1 -= X2 * U12^T,  U12 = lt[0:n1, n1:n]
+    NNGP_TRY(launch_gemm_nt_f32(b, ldb, b + n1, ldb, lt + n1, ldl, m, n1, n2, -1.0f, 1.0f, false, s));
+    return trsm_rut_f32(b, ldb, m, lt, ldl, dinvt, n1, s);
 }
 
 static int potrf_rec(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,

@@ -176,6 +176,14 @@ static int trsm_rlt_batched(float* b, int64_t ldb, int64_t sb, int64_t m, const 
     return trsm_rlt_batched(b + n1, ldb, sb, m, l + n1 * ldl + n1, ldl, sl, dinv + (n1 / TB) * TB * TB, sd, n2, batch, s);
 }
 
+int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_t count, hipStream_t s) {
+    NNGP_REQUIRE(bs % 32 == 0 && count > 0 && count <= 65535, "transpose_blocks: bad arguments");
+    hipLaunchKernelGGL(k_transpose_blocks, dim3((unsigned)(bs / 32), (unsigned)(bs / 32), (unsigned)count), dim3(256), 0, s,
+                       src, dst, bs);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int64_t triinv_block(int64_t np) { return np < 1024 ? np : 1024; }
 
 // Inverts the diagonal blocks (size bs, tail np % bs) of the float32 factor: T_J = L_JJ^-T by a batched

@@ -68,6 +68,11 @@ class GPModel:
     def solve(self, max_iters: int = 0, tol: float = 0.0):
         _lib.check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 
+    def set_refine(self, sweeps: int):
+        """float64 correction sweeps of the posterior covariance (default 1; 0 = float32 solve only)."""
+        _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
+        return self
+
     def fit(self, x, y):
         self.set_train(x, y)
         self.build_rows(0, self.n)

@@ -37,6 +37,15 @@ def gemm_nt(c, a, b, alpha, beta, lower_only=False):
     torch.cuda.synchronize()
 
 
+def gemm_nt_f64(c, cin, a, b, alpha, beta):
+    lib = _lib.load()
+    m, k = a.shape
+    n = b.shape[0]
+    _lib.check(lib.nngp_gemm_nt_f64(_lib.ptr(c), c.stride(0), _lib.ptr(cin), 0 if cin is None else cin.stride(0), _lib.ptr(a),
+                                    a.stride(0), _lib.ptr(b), b.stride(0), m, n, k, alpha, beta, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+
+
 def potrf(a):
     """a: [n, n] float32 cuda tensor (lower triangle used); returns (dinv [n/128,128,128], clamped)."""
     lib = _lib.load()

@@ -139,7 +139,8 @@ def test_gemm_random(m, n, k):
     G.gemm_nt(c, a, b, -1.0, 1.0)
     ref = c0.double() - a.double() @ b.double().T
     bound = c0.abs().double() + a.abs().double() @ b.abs().double().T   # sum |terms| per element
-    assert ((c.double() - ref).abs() <= 1e-6 * bound).all(), ((c.double() - ref).abs() / bound).max().item()
+    tol = 4 * (k + 1) ** 0.5 * 6e-8  # random-walk bound of a k-long fp32 fma chain, relative to sum |terms|
+    assert ((c.double() - ref).abs() <= tol * bound).all(), ((c.double() - ref).abs() / bound).max().item()
     # strided views (sub-blocks of a larger matrix) and the SYRK form
     big = torch.randn((m + 128, k + 256), device=G.dev())
     av = big[128:, 256:]
@@ -148,7 +149,7 @@ def test_gemm_random(m, n, k):
     ref = (av.double() @ av.double().T)
     tile_lower = (torch.arange(m, device=G.dev())[:, None] // 128) >= (torch.arange(m, device=G.dev())[None, :] // 128)
     bound = av.abs().double() @ av.abs().double().T
-    assert ((c.double() - ref).abs() <= 1e-6 * bound)[tile_lower].all()
+    assert ((c.double() - ref).abs() <= tol * bound)[tile_lower].all()
     assert torch.all(c[~tile_lower] == 0)  # tiles above the diagonal are never touched
 
 
@@ -159,6 +160,26 @@ def test_gemm_in_place_inverse_block(rows):
     ref = bmat.double() @ inv.double().T
     G.gemm_nt(bmat, bmat, inv, 1.0, 0.0)
     assert (bmat.double() - ref).abs().max().item() < 1e-4
+
+
+def test_gemm_f64_mfma():
+    """float64 MFMA GEMM: exact on small integers (asymmetric operands catch C/D lane-map mistakes), 1e-13 on random."""
+    torch.manual_seed(7)
+    m, n, k = 256, 384, 144
+    a = torch.randint(-8, 9, (m, k), device=G.dev()).double(); b = torch.randint(-8, 9, (n, k), device=G.dev()).double()
+    cin = torch.randint(-8, 9, (m, n), device=G.dev()).double()
+    c = torch.full((m, n), float("nan"), dtype=torch.float64, device=G.dev())
+    G.gemm_nt_f64(c, cin, a, b, -1.0, 1.0)
+    assert torch.equal(c, cin - a @ b.T)
+    eye = torch.zeros((128, 128), dtype=torch.float64, device=G.dev()); eye.fill_diagonal_(1.0)
+    bb = torch.randn((256, 128), dtype=torch.float64, device=G.dev())
+    c = torch.empty((128, 256), dtype=torch.float64, device=G.dev())
+    G.gemm_nt_f64(c, None, eye, bb, 1.0, 0.0)
+    assert torch.equal(c, bb.T.contiguous())
+    a = torch.randn((384, 1024), dtype=torch.float64, device=G.dev()); b = torch.randn((256, 1024), dtype=torch.float64, device=G.dev())
+    c = torch.randn((384, 256), dtype=torch.float64, device=G.dev()); ref = 0.5 * c + 2.0 * a @ b.T
+    G.gemm_nt_f64(c, c, a, b, 2.0, 0.5)
+    assert (c - ref).abs().max().item() < 1e-11
 
 
 # ---------------------------------------------------------------------------- Cholesky / TRSM
@@ -216,7 +237,7 @@ def _fit_and_check(x, y, xt, n_relu=1, get="nngp", w=1.0, b=0.0):
     info = model.info()
     post = o.Posterior(x, y, a, diag_reg=1e-3)
     K = post._factor(get)[0]
-    np.testing.assert_allclose(info["reg"], 1e-3 * np.trace(K) / x.shape[0], rtol=1e-12)
+    np.testing.assert_allclose(info["reg"], 1e-3 * np.trace(K) / x.shape[0], rtol=1e-8)  # oracle diag carries sqrt(rounding) noise
     assert info["clamped_pivots"] == 0 and info["rel_residual"] <= 1e-10, info
     alpha = model.alpha().cpu().numpy()
     assert G.rel_l2(alpha, post._factor(get)[2]) < 1e-6
@@ -232,17 +253,25 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     mean, var = model.predict(xt, cov="diag")
     l2, elem = G.mean_gate(mean, mean_ref)
     assert l2 < 1e-6 and elem < 1e-6, (l2, elem, info)
-    np.testing.assert_allclose(var, np.diag(cov_ref), rtol=1e-3, atol=1e-6 * np.abs(cov_ref).max())
+    np.testing.assert_allclose(var, np.diag(cov_ref), rtol=1e-5, atol=1e-9 * np.abs(cov_ref).max())
     mean2, cov = model.predict(xt, cov="full")
     assert np.array_equal(mean2, mean)
-    assert np.abs(cov - cov_ref).max() < 1e-3 * np.abs(np.diag(cov_ref)).max()
+    assert np.abs(cov - cov_ref).max() < 1e-6 * np.abs(np.diag(cov_ref)).max()
+    np.testing.assert_allclose(np.diag(cov), var, rtol=1e-9)
+    # float32-only covariance (set_refine(0)): accurate to ~cond*eps32 of the PRIOR variance only
+    model.set_refine(0)
+    var32 = model.predict(xt, cov="diag")[1]
+    _, cov32 = model.predict(xt, cov="full")
+    prior = o.diag_kernel(np.sum(xt * xt, axis=1) / d, o.make_arch(n_relu))[0]
+    assert np.abs(var32 - np.diag(cov_ref)).max() < 1e-4 * prior.max()
+    assert np.abs(cov32 - cov_ref).max() < 1e-4 * prior.max()
+    model.set_refine(1)
     assert np.array_equal(model.predict(xt, cov=False), mean)
     # x_test=None: predictions on the training rows (estimator.py:37-40)
     mean_tr, var_tr = model.predict(None, cov="diag")
     mtr_ref, ctr_ref = post.predict(None, "nngp", True)
     assert G.mean_gate(mean_tr, mtr_ref)[0] < 1e-6
-    # on the training rows the posterior variance is a small difference of large numbers: float32 solve -> 1e-2
-    np.testing.assert_allclose(var_tr, np.diag(ctr_ref), rtol=1e-2, atol=1e-6 * np.abs(ctr_ref).max())
+    np.testing.assert_allclose(var_tr, np.diag(ctr_ref), rtol=1e-4, atol=1e-9 * np.abs(ctr_ref).max())
 
 
 def test_fit_predict_ntk_mean_and_two_outputs():
@@ -252,7 +281,17 @@ def test_fit_predict_ntk_mean_and_two_outputs():
     model, post, _ = _fit_and_check(x, y2, xt, n_relu=2, get="ntk", w=1.2, b=0.1)
     mean = model.predict(xt, cov=False)
     assert mean.shape == (50, 2)
-    assert G.mean_gate(mean, post.predict(xt, "ntk", False))[0] < 1e-6
+    m_ref, c_ref = post.predict(xt, "ntk", True)
+    assert G.mean_gate(mean, m_ref)[0] < 1e-6
+    # NTK ensemble covariance: K_tt + Z K_dd Z^T - (K_td Z^T + h.c.)
+    _, var = model.predict(xt, cov="diag")
+    np.testing.assert_allclose(var, np.diag(c_ref), rtol=1e-4, atol=1e-8 * np.abs(c_ref).max())
+    _, cov = model.predict(xt, cov="full")
+    assert np.abs(cov - c_ref).max() < 1e-5 * np.abs(np.diag(c_ref)).max()
+    mtr, vtr = model.predict(None, cov="diag")
+    mtr_ref, ctr_ref = post.predict(None, "ntk", True)
+    assert G.mean_gate(mtr, mtr_ref)[0] < 1e-6
+    np.testing.assert_allclose(vtr, np.diag(ctr_ref), rtol=1e-3, atol=1e-7 * np.abs(ctr_ref).max())
 
 
 def test_forest_golden_config1(golden_dir):
@@ -265,11 +304,12 @@ def test_forest_golden_config1(golden_dir):
         assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
         if get == "nngp":
             mean, var = model.predict(g["X_test"], cov="diag")
-            np.testing.assert_allclose(var, g["nngp_var"], rtol=1e-3)
+            np.testing.assert_allclose(var, g["nngp_var"], rtol=1e-5)
             _, cov = model.predict(g["X_test"][:16], cov="full")
-            assert np.abs(cov - g["nngp_cov16"]).max() < 1e-3 * np.abs(np.diag(g["nngp_cov16"])).max()
+            assert np.abs(cov - g["nngp_cov16"]).max() < 1e-6 * np.abs(np.diag(g["nngp_cov16"])).max()
         else:
-            mean = model.predict(g["X_test"], cov=False)
+            mean, var = model.predict(g["X_test"], cov="diag")
+            np.testing.assert_allclose(var, g["ntk_var"], rtol=1e-4)
         l2, elem = G.mean_gate(mean, g[get + "_mean"])
         assert l2 < 1e-6 and elem < 1e-5, (get, l2, elem, info)
         from nngp_src_amd.util import q_error_profile
@@ -291,7 +331,7 @@ def test_medium_size_against_c_oracle():
     mean, var = model.predict(xt, cov="diag")
     l2, elem = G.mean_gate(mean, mean_ref)
     assert info["clamped_pivots"] == 0 and l2 < 1e-6 and elem < 1e-6, (l2, elem, info)
-    np.testing.assert_allclose(var, var_ref, rtol=2e-3, atol=1e-6 * np.abs(var_ref).max())
+    np.testing.assert_allclose(var, var_ref, rtol=1e-4, atol=1e-9 * np.abs(var_ref).max())
     assert info["refine_iters"] <= 20, info
 
 
