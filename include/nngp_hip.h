@@ -57,6 +57,9 @@ typedef struct nngp_fit_info {
 typedef struct nngp_model nngp_model;
 
 int nngp_version(void);
+/* Timing-experiment switches used by scripts/microbench.py (ablations that produce WRONG results on purpose);
+ * every key is 0 in normal operation.  Not part of the stable interface. */
+int nngp_debug_set(int32_t key, int32_t value);
 const char* nngp_last_error(void);
 
 /* ---- a1: kernel_fn(x1, x2, get) ---------------------------------------------------------------

@@ -20,7 +20,7 @@ MAX_DENSE = 16
 
 # every symbol include/nngp_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "nngp_version", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
+    "nngp_version", "nngp_debug_set", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
@@ -60,6 +60,7 @@ def load():
     archp = ctypes.POINTER(NngpArch)
     lib.nngp_version.restype = ctypes.c_int
     lib.nngp_last_error.restype = ctypes.c_char_p
+    lib.nngp_debug_set.argtypes = [i32, i32]
     lib.nngp_kernel_build.argtypes = [vp, i64, vp, i64, i32, archp, i32, vp, vp, i64, i64, i64, vp]
     lib.nngp_kernel_diag.argtypes = [vp, i64, i32, archp, vp, vp, vp]
     lib.nngp_model_create.argtypes = [ctypes.POINTER(vp), i64, i64, i32, i32, archp, i32, dbl, i32]

@@ -231,6 +231,12 @@ extern "C" {
 
 int nngp_version(void) { return NNGP_ABI_VERSION; }
 
+int nngp_debug_set(int32_t key, int32_t value) {
+    NNGP_REQUIRE(key >= 0 && key < 8, "debug_set: key out of range");
+    g_debug[key] = value;
+    return 0;
+}
+
 const char* nngp_last_error(void) { return g_err; }
 
 int nngp_kernel_diag(const double* x, int64_t n, int32_t d, const nngp_arch* arch, double* diag_nngp,

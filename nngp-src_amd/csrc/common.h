@@ -12,6 +12,7 @@ namespace nngp {
 constexpr int TB = 128;  // Cholesky / GEMM tile edge; all float32 device matrices are padded to it
 
 void set_error(const char* fmt, ...);
+extern int g_debug[8];  // timing experiments (nngp_debug_set); all zero in normal operation
 
 #define NNGP_HIP_CHECK(expr)                                                              \
     do {                                                                                  \

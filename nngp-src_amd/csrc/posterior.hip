@@ -135,12 +135,13 @@ __global__ __launch_bounds__(256) void k_rowdot_f64(const double* __restrict__ z
     if (threadIdx.x == 0) out[row] = base[row] + sign * (red[0] + red[1] + red[2] + red[3]);
 }
 
-// dst[m, m] (dense) = src[m, m] (leading dimension lds)
+// dst[m, m] (dense) = (src + src^T) / 2 of src[m, m] (leading dimension lds).  The symmetric part is where the
+// first-order error of the refined solve cancels for off-diagonal covariance entries as well.
 __global__ __launch_bounds__(256) void k_copy_mat_f64(const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
                                                       int64_t m) {
     const int64_t row = blockIdx.y;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c < m) dst[row * m + c] = src[row * lds + c];
+    if (c < m) dst[row * m + c] = 0.5 * (src[row * lds + c] + src[c * lds + row]);
 }
 
 // dst = src^T for a square float32 matrix (32 x 32 tiles through LDS)

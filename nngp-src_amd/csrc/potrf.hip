@@ -17,6 +17,8 @@
 
 namespace nngp {
 
+int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // timing experiments only (nngp_debug_set); 0 = product behaviour
+
 namespace {
 
 constexpr int LS = 129;  // LDS row stride (floats)
@@ -62,7 +64,7 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float* dinv, int32_t* clamped,
-                                                    float pivot_floor) {
+                                                    float pivot_floor, int dbg) {
     __shared__ float Ls[128 * LS];
     __shared__ float Xs[128 * LS];
     __shared__ float colbuf[64];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
     for (int jb = 0; jb < 4; ++jb) {
         float* Djj = Ls + (jb * 32) * LS + jb * 32;
         float* Xjj = Xs + (jb * 32) * LS + jb * 32;
-        if (wave == 0) {
+        if (wave == 0 && !(dbg & 1)) {
             // One wave factors and inverts the 32x32 diagonal sub-block.  Lane i owns row i in registers; the
             // values every lane needs (pivot, column j) travel through a 32-float LDS line read back as
             // broadcasts -- an LDS round trip per column instead of ~500 v_readlane + hazard nops.
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
         }
         __syncthreads();
         // ---- sub-blocks below the diagonal: A[ib][jb] <- A[ib][jb] * Dinv^T ----
-        {
+        if (!(dbg & 4)) {
             const int ib = jb + 1 + wave;
             if (ib < 4) {
                 float* Aij = Ls + (ib * 32) * LS + jb * 32;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
         }
         __syncthreads();
         // ---- trailing sub-blocks: A[ib][kb] -= A[ib][jb] * A[kb][jb]^T, jb < kb <= ib ----
-        {
+        if (!(dbg & 4)) {
             int cnt = 0;
             for (int ib = jb + 1; ib < 4; ++ib)
                 for (int kb = jb + 1; kb <= ib; ++kb, ++cnt) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
     }
 
     // ---- assemble the 128x128 inverse: X[ib][jb] = -Dinv_ii * sum_{k=jb}^{ib-1} L[ib][k] X[k][jb] ----
-    for (int dist = 1; dist < 4; ++dist) {
+    for (int dist = 1; dist < ((dbg & 2) ? 1 : 4); ++dist) {
         const int ib = dist + wave, jb = wave;  // wave w owns block (dist + w, w)
         const bool active = ib < 4;
         float* scratch = Xs + (jb * 32) * LS + ib * 32;  // the (zero) upper block (jb, ib), valid when active
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
 }  // namespace
 
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s) {
-    hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor);
+    hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, g_debug[0]);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

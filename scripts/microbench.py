@@ -59,6 +59,15 @@ def main():
         ms -= cp
         out["potrf_%d" % n] = {"ms": round(ms, 4), "tflops": round(n ** 3 / 3 / ms / 1e9, 2), "clamped": int(clamped.item())}
         del base, spd, a
+    # leaf ablations (dbg bit 1: skip diagonal factor/inverse, 2: skip inverse assembly, 4: skip MFMA sub-block updates)
+    base = torch.randn((128, 128), device=dev)
+    spd = base @ base.T / 128 + torch.eye(128, device=dev) * 2.0
+    a = spd.clone(); dinv = torch.empty((1, 128, 128), device=dev); clamped = torch.zeros(1, dtype=torch.int32, device=dev)
+    for dbg in (0, 1, 2, 4, 7):
+        lib.nngp_debug_set(0, dbg)
+        ms = timeit(lambda: _lib.check(lib.nngp_potrf_f32(_lib.ptr(a), 128, 128, _lib.ptr(dinv), _lib.ptr(clamped), _lib.stream_ptr())), reps=50)
+        out["leaf_dbg%d_us" % dbg] = round(ms * 1e3, 2)
+    lib.nngp_debug_set(0, 0)
     print(json.dumps(out, indent=1))
 
 

@@ -147,10 +147,12 @@ def test_gemm_random(m, n, k):
     c = torch.zeros((m, m), device=G.dev())
     G.gemm_nt(c, av, av, 1.0, 0.0, lower_only=True)
     ref = (av.double() @ av.double().T)
-    tile_lower = (torch.arange(m, device=G.dev())[:, None] // 128) >= (torch.arange(m, device=G.dev())[None, :] // 128)
+    idx = torch.arange(m, device=G.dev())
+    elem_lower = idx[:, None] >= idx[None, :]                 # what the Cholesky reads back
+    tile_upper = (idx[:, None] // 128) < (idx[None, :] // 128)  # 128-tiles strictly above the diagonal
     bound = av.abs().double() @ av.abs().double().T
-    assert ((c.double() - ref).abs() <= tol * bound)[tile_lower].all()
-    assert torch.all(c[~tile_lower] == 0)  # tiles above the diagonal are never touched
+    assert ((c.double() - ref).abs() <= tol * bound)[elem_lower].all()
+    assert torch.all(c[tile_upper] == 0)  # tiles above the diagonal are never touched
 
 
 @pytest.mark.parametrize("rows", [128, 512, 24576 + 128])  # 64x128 and 128x128 workgroup tiles
@@ -257,6 +259,7 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     mean2, cov = model.predict(xt, cov="full")
     assert np.array_equal(mean2, mean)
     assert np.abs(cov - cov_ref).max() < 1e-6 * np.abs(np.diag(cov_ref)).max()
+    assert np.array_equal(cov, cov.T)
     np.testing.assert_allclose(np.diag(cov), var, rtol=1e-9)
     # float32-only covariance (set_refine(0)): accurate to ~cond*eps32 of the PRIOR variance only
     model.set_refine(0)
