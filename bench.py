@@ -149,6 +149,11 @@ def main():
         elapsed = float(t.item())
 
     info = model.info()
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
+    if os.path.exists(tpath):  # HBM bytes of the float32 GEMM + leaf kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
+        traffic = json.load(open(tpath)).get("f32_gemm_and_leaf_bytes")
+        traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % args.config
     if rank == 0:
         fl = flop_model(n, d, m, n_relu)
         ms = elapsed / args.steps * 1e3
@@ -164,7 +169,8 @@ def main():
                        "parallelism": "row-block kernel shard x%d + all-gather, replicated Cholesky" % world if world > 1 else "single GPU",
                        "precision": "float64 kernel build + CG residual, float32 MFMA Cholesky (preconditioner), float64 means"},
             "roofline": {"bound": "mfma", "achieved": round(chol_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(chol_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(chol_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "Cholesky stage (k_gemm_nt_f32 SYRK/GEMM launches + k_potrf_leaf), F_C = N^3/3 + N^2/2 + N/6 per step",
                          "north_star_frac_build_plus_cholesky": round((fl["kernel_build"] + fl["cholesky"]) /
                                                                        ((st["kernel_build"] + st["cholesky"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},

@@ -85,7 +85,7 @@ struct nngp_model {
     float* vvt32 = nullptr;      // [fullp, fullp]
 
     // float64 refinement of the posterior covariance (grown on demand)
-    int var_refine = 1;          // correction sweeps before the second-order variance formula (0 = float32 only)
+    int var_refine = 1;          // covariance precision level, see nngp_model_set_refine
     float* lt32 = nullptr;       // [np_cap, np_cap] L^T, built lazily after a fit
     float* dinvt = nullptr;      // transposed inverted 128-blocks
     bool lt_ready = false;
@@ -195,14 +195,14 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
 }
 
-// z64 <- rows of `rhs` [mp, np] times (K + reg I)^-1, float32 solves corrected by `sweeps` float64 residual sweeps.
-// On return r64 holds the residual rhs - z64 (K + reg I) of the returned z64.
-int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps, hipStream_t s) {
+// z64 <- rows of `rhs` [mp, np] times (K + reg I)^-1: float32 solves corrected by `sweeps` float64 residual sweeps.
+// final_residual: also leave r64 = rhs - z64 (K + reg I) for the returned z64 (one more float64 product).
+int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps, bool final_residual, hipStream_t s) {
     const int64_t np = m->np;
     NNGP_TRY(launch_convert_f64_f32(rhs, np, m->b32, np, mp, np, mp, np, s));
     NNGP_TRY(apply_inverse_f32(m, mp, s));
     NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));
-    for (int it = 0;; ++it) {
+    for (int it = 0; it < sweeps + (final_residual ? 1 : 0); ++it) {
         NNGP_TRY(launch_gemm_nt_f64(m->r64, np, rhs, np, m->z64, np, m->k64, np, mp, np, np, -1.0, 1.0, s));
         NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
         if (it == sweeps) break;
@@ -465,7 +465,7 @@ int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream) {
 }
 
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps) {
-    NNGP_REQUIRE(m != nullptr && sweeps >= 0 && sweeps <= 8, "set_refine: sweeps must be in [0, 8]");
+    NNGP_REQUIRE(m != nullptr && sweeps >= 0 && sweeps <= 8, "set_refine: level must be in [0, 8]");
     m->var_refine = sweeps;
     return 0;
 }
@@ -523,13 +523,22 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     NNGP_TRY(ensure_lt(m, s));
     NNGP_TRY(ensure_refine_capacity(m, mp));
     if (!is_ntk) {
-        // NNGP: cov_ij = K_tt,ij - k_i^T A^-1 k_j.  With Z ~ K_td A^-1 and R = K_td - Z A (float64),
-        //   k_i^T A^-1 k_j = z_i . (k_j + r_j) + O(|error|^2): the first-order error of Z cancels.
-        NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine, s));
-        if (!full) return launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s);
-        NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, 1.0, np, mp, np, s));  // G = K_td + R
+        // NNGP: cov_ij = K_tt,ij - k_i^T A^-1 k_j with Z ~ K_td A^-1 (float32 solve + float64 correction sweeps).
+        //   level 1: one sweep, cov = K_tt - sym(Z K_dt)                       (error ~ rho * float32 error)
+        //   level L >= 2: L-1 sweeps, then with R = K_td - Z A:  k_i^T A^-1 k_j = sym(z_i . (k_j + r_j)) + O(err^2)
+        const int level = m->var_refine;
+        const bool second_order = level >= 2;
+        NNGP_TRY(refined_solve_rows(m, ktd, mp, second_order ? level - 1 : 1, second_order, s));
+        if (!full)
+            return launch_rowdot_f64(m->z64, ktd, 1.0, second_order ? m->r64 : nullptr, np, mt, np, m->tt_diag, -1.0,
+                                     var_or_cov, s);
+        const double* g = ktd;
+        if (second_order) {
+            NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, 1.0, np, mp, np, s));  // G = K_td + R
+            g = m->r64;
+        }
         NNGP_TRY(build_ktt());
-        NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->z64, np, m->r64, np, mp, mp, np, -1.0, 1.0, s));
+        NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->z64, np, g, np, mp, mp, np, -1.0, 1.0, s));
         return launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s);
     }
 
@@ -561,7 +570,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(build_cross(m, xt, qt, mt, mp, true, m->ktd_aux, s));
         ktd_n = m->ktd_aux;
     }
-    NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine + 1, s));  // no error cancellation here: one more sweep
+    NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine < 2 ? 2 : m->var_refine, false, s));  // no error cancellation: >= 2 sweeps
     NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd
     if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
         return launch_rowdot_f64(m->z64, ktd_n, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);

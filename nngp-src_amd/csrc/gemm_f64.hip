@@ -26,12 +26,14 @@ __device__ __forceinline__ int lds_off64(int row, int ch) { return row * 128 + (
 
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, const double* Cin, int64_t ldcin,
                                                         const double* A, int64_t lda, const double* B, int64_t ldb,
-                                                        int tiles_n, int nk, double alpha, double beta) {
+                                                        int tiles_m, int nk, double alpha, double beta) {
     __shared__ __attribute__((aligned(16))) double smem[2 * DSTAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bi = blockIdx.x / tiles_n, bj = blockIdx.x % tiles_n;
+    // row tile is the fast index: the workgroups that share one 128-row panel of B (the big symmetric kernel matrix)
+    // are dispatched together, so the panel is fetched from HBM once and served from L2 / Infinity Cache after that
+    const int bi = blockIdx.x % tiles_m, bj = blockIdx.x / tiles_m;
     const double* Ab = A + (int64_t)bi * DBM * lda;
     const double* Bb = B + (int64_t)bj * DBN * ldb;
 
@@ -129,7 +131,7 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
     const int64_t tm = m / DBM, tn = n / DBN;
     NNGP_REQUIRE(tm * tn < 2147483647LL, "gemm_nt_f64: grid too large");
     hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
-                       a, lda, b, ldb, (int)tn, (int)(k / DBK), alpha, beta);
+                       a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -106,7 +106,8 @@ def test_gemm_exact_on_integers_asymmetric():
 
 def test_gemm_is_a_k_ordered_fp32_fma_chain():
     """f32-input MFMA is an exact fp32 fma chain (guide: MFMA numerics); emulate the kernel's k order on the host
-    and require bit-for-bit equality.  Order: per 32-wide K tile, per 8-wide step s, per kk: k = 8s+kk then 8s+4+kk."""
+    and require bit-for-bit equality.  Order: 32-wide K tiles from the high end of K down (small Cholesky terms
+    first), inside a tile per 8-wide step s, per kk: k = 8s+kk then 8s+4+kk."""
     torch.manual_seed(5)
     m = n = 128
     k = 256
@@ -123,8 +124,9 @@ def test_gemm_is_a_k_ordered_fp32_fma_chain():
             acc = (acc.astype(np.float64) + prod).astype(np.float32)                               # one rounding (fma)
         return acc
 
-    base = [32 * t + 8 * s + kk + 4 * h for t in range(k // 32) for s in range(4) for kk in range(4) for h in (0, 1)]
-    alt = [32 * t + 8 * s + kk + 4 * h for t in range(k // 32) for s in range(4) for kk in range(4) for h in (1, 0)]
+    tiles = list(reversed(range(k // 32)))
+    base = [32 * t + 8 * s + kk + 4 * h for t in tiles for s in range(4) for kk in range(4) for h in (0, 1)]
+    alt = [32 * t + 8 * s + kk + 4 * h for t in tiles for s in range(4) for kk in range(4) for h in (1, 0)]
     ok = np.array_equal(got, chain(base)) or np.array_equal(got, chain(alt))
     if not ok:
         d0 = np.abs(got - chain(base)).max()
@@ -261,6 +263,11 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     assert np.abs(cov - cov_ref).max() < 1e-6 * np.abs(np.diag(cov_ref)).max()
     assert np.array_equal(cov, cov.T)
     np.testing.assert_allclose(np.diag(cov), var, rtol=1e-9)
+    model.set_refine(3)  # two sweeps + second-order formula
+    var3 = model.predict(xt, cov="diag")[1]
+    _, cov3 = model.predict(xt, cov="full")
+    np.testing.assert_allclose(var3, np.diag(cov_ref), rtol=1e-7, atol=1e-10 * np.abs(cov_ref).max())
+    assert np.abs(cov3 - cov_ref).max() < 1e-8 * np.abs(np.diag(cov_ref)).max()
     # float32-only covariance (set_refine(0)): accurate to ~cond*eps32 of the PRIOR variance only
     model.set_refine(0)
     var32 = model.predict(xt, cov="diag")[1]
