@@ -83,12 +83,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # NNGP_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
+        # devices, collectives staged through the host); the real runs use nccl = RCCL over xGMI.
+        backend = os.environ.get("NNGP_DIST_BACKEND", "nccl")
+        local_dev = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    if os.environ.get("NNGP_DEBUG"):  # timing experiments only, e.g. NNGP_DEBUG="2=1" disables the look-ahead Cholesky
+        from nngp_src_amd import _lib
+        for kv in os.environ["NNGP_DEBUG"].split(","):
+            k, v = kv.split("=")
+            _lib.load().nngp_debug_set(int(k), int(v))
     n, d, n_relu, get, m, join_block, desc = CONFIGS[args.config]
     x, y = synth.synthetic_queries(n, d, seed=0, join_block=join_block)
     xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
@@ -176,7 +188,8 @@ def main():
                                                                        ((st["kernel_build"] + st["cholesky"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "stages_ms": {k: round(v, 3) for k, v in st.items()},
             "fit_info": {"cg_iters": info["refine_iters"], "rel_residual": info["rel_residual"],
-                         "clamped_pivots": info["clamped_pivots"], "reg": info["reg"]},
+                         "clamped_pivots": info["clamped_pivots"], "reg": info["reg"],
+                         "alpha_l2": float(torch.linalg.vector_norm(model.alpha()).item())},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(n_relu, get)

@@ -119,9 +119,11 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
 /* Precision level of the posterior covariance (means are float64-accurate at every level).  Z ~ K_td (K + reg I)^-1
  * comes from the float32 factor; each correction sweep costs one [mt, N] x [N, N] float64 MFMA product and one pair
  * of float32 triangular solves and shrinks the error by rho ~ 1e-3 (N = 32768):
- *   0      float32 only, cov = K_tt - V^T V                      (measured: <= 0.7 % of the posterior variance)
- *   1      one sweep, cov = K_tt - sym(Z K_dt)                   (default; ~1e-5 relative)
- *   L >= 2 L-1 sweeps + the second-order formula sym(z_i . (k_j + r_j)), one more product   (~1e-7 and below) */
+ * (max relative error of diag(cov) measured at N = 32768, d = 128, profiles/r1e_var_study.json):
+ *   0      float32 only, cov = K_tt - V^T V                                          6e-3
+ *   1      one sweep, cov = K_tt - sym(Z K_dt)                                       1e-3
+ *   2      one sweep + the second-order formula sym(z_i . (k_j + r_j)) (default)     5e-7
+ *   L > 2  L-1 sweeps + the second-order formula                                     1e-10 at L = 3 */
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps);
 
 /* ---- building blocks exported for parity tests and the integration notes ----------------------

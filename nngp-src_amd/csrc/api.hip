@@ -73,6 +73,7 @@ struct nngp_model {
     double* alpha = nullptr;  // [n_cap, ny]
     PcgWork pcg{};
     TriInv tri{};
+    LookAhead* la = nullptr;
 
     // predict-side buffers (grown on demand when m > m_cap)
     double* xt_q = nullptr;      // [m_cap]
@@ -85,7 +86,7 @@ struct nngp_model {
     float* vvt32 = nullptr;      // [fullp, fullp]
 
     // float64 refinement of the posterior covariance (grown on demand)
-    int var_refine = 1;          // covariance precision level, see nngp_model_set_refine
+    int var_refine = 2;          // covariance precision level, see nngp_model_set_refine
     float* lt32 = nullptr;       // [np_cap, np_cap] L^T, built lazily after a fit
     float* dinvt = nullptr;      // transposed inverted 128-blocks
     bool lt_ready = false;
@@ -109,6 +110,7 @@ struct nngp_model {
         dev_free(pcg.f32a); dev_free(pcg.f32b); dev_free(pcg.f32c); dev_free(pcg.scal);
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
+        lookahead_destroy(la);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
@@ -336,6 +338,7 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         set_error("model_create: hipHostMalloc failed");
         rc = -1;
     }
+    if (rc == 0) rc = lookahead_create(&m->la);
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {
         delete m;
@@ -398,7 +401,7 @@ int nngp_model_factor(nngp_model* m, void* stream) {
     NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
-    NNGP_TRY(potrf_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), s));
+    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, s));
     m->tri.bs = triinv_block(m->np);
     NNGP_TRY(triinv_build(m->a32, m->np, m->dinv, m->np, m->tri, s));
     m->factored = true;

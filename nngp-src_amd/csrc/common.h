@@ -85,6 +85,17 @@ int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, fl
 int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
                  hipStream_t s);
 
+struct LookAhead {  // streams and events of the look-ahead Cholesky (one per model)
+    static constexpr int kMaxSteps = 64;
+    hipStream_t panel = nullptr, update = nullptr;
+    bool masked = false;  // streams own disjoint CU sets (hipExtStreamCreateWithCUMask)
+    hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
+    hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};
+};
+int lookahead_create(LookAhead** out);
+void lookahead_destroy(LookAhead* la);
+int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
+                        LookAhead* la, hipStream_t user);
 int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
                  hipStream_t s);
 

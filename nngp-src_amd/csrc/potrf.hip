@@ -13,6 +13,8 @@
 // trailing sub-blocks updated with v_mfma_f32_32x32x2_f32.  The 128x128 inverse is assembled from the
 // 32x32 inverses by block forward substitution on the matrix cores.  LDS row stride is 129 floats, which
 // makes row-wise and column-wise 4-byte fragment reads conflict free.
+#include <new>
+
 #include "common.h"
 
 namespace nngp {
@@ -21,12 +23,13 @@ int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // timing experiments only (nngp_deb
 
 namespace {
 
-constexpr int LS = 129;  // LDS row stride (floats)
+constexpr int LS = 33;            // LDS row stride of one 32x32 sub-block (odd: row- and column-wise reads conflict free)
+constexpr int BLK = 32 * LS;      // floats per packed sub-block
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
+// Only the 10 sub-blocks on or below the diagonal are kept in LDS (L and X = L^-1 are lower triangular):
+// 2 x 10 x 32 x 33 floats = 84.5 KB, so the leaf co-resides with a 64 KB GEMM workgroup on the same CU.
+__device__ __forceinline__ constexpr int blk(int ib, int jb) { return ib * (ib + 1) / 2 + jb; }
 
 // acc += sign * A_blk(32x32) * op(B_blk);  NN: op(B) = B,  NT: op(B) = B^T.  Blocks live in LDS, stride LS.
 template <bool NN>
@@ -63,54 +66,59 @@ __device__ __forceinline__ f32x16 zero16() {
     return v;
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float* dinv, int32_t* clamped,
-                                                    float pivot_floor, int dbg) {
-    __shared__ float Ls[128 * LS];
-    __shared__ float Xs[128 * LS];
+                                                       float pivot_floor, int dbg) {
+    __shared__ float Lb[10 * BLK];
+    __shared__ float Xb[10 * BLK];
+    __shared__ float Tb[3 * BLK];   // scratch of the inverse assembly (one block per active wave)
     __shared__ float colbuf[64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = tid >> 3, lc = (tid & 7) * 4;  // this thread's (row, first column) inside a 32x32 sub-block
 
     {
-        // 16 independent 16-byte loads per thread, issued back to back (one HBM round trip for the whole block)
-        float4 v[16];
+        // one 16-byte load per thread per lower sub-block, all 10 issued back to back
+        float4 v[10];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int idx = (tid + 256 * e) * 4;
-            const int r = idx >> 7, c = idx & 127;
-            v[e] = *reinterpret_cast<const float4*>(A + (int64_t)r * ld + c);  // upper entries are masked below
-        }
+        for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int idx = (tid + 256 * e) * 4;
-            const int r = idx >> 7, c = idx & 127;
-            float* lp = Ls + r * LS + c;
-            float* xp = Xs + r * LS + c;
-            lp[0] = (c <= r) ? v[e].x : 0.0f;
-            lp[1] = (c + 1 <= r) ? v[e].y : 0.0f;
-            lp[2] = (c + 2 <= r) ? v[e].z : 0.0f;
-            lp[3] = (c + 3 <= r) ? v[e].w : 0.0f;
-            xp[0] = xp[1] = xp[2] = xp[3] = 0.0f;
-        }
+            for (int jb = 0; jb <= ib; ++jb)
+                v[blk(ib, jb)] = *reinterpret_cast<const float4*>(A + (int64_t)(ib * 32 + lr) * ld + jb * 32 + lc);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb <= ib; ++jb) {
+                const float4 t = v[blk(ib, jb)];
+                float* lp = Lb + blk(ib, jb) * BLK + lr * LS + lc;
+                float* xp = Xb + blk(ib, jb) * BLK + lr * LS + lc;
+                const bool diag = (ib == jb);  // strictly-upper entries of a diagonal sub-block are not part of A
+                lp[0] = (!diag || lc + 0 <= lr) ? t.x : 0.0f;
+                lp[1] = (!diag || lc + 1 <= lr) ? t.y : 0.0f;
+                lp[2] = (!diag || lc + 2 <= lr) ? t.z : 0.0f;
+                lp[3] = (!diag || lc + 3 <= lr) ? t.w : 0.0f;
+                xp[0] = xp[1] = xp[2] = xp[3] = 0.0f;
+            }
     }
     __syncthreads();
 
     int nclamp = 0;
+#pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
-        float* Djj = Ls + (jb * 32) * LS + jb * 32;
-        float* Xjj = Xs + (jb * 32) * LS + jb * 32;
+        float* Djj = Lb + blk(jb, jb) * BLK;
+        float* Xjj = Xb + blk(jb, jb) * BLK;
         if (wave == 0 && !(dbg & 1)) {
             // One wave factors and inverts the 32x32 diagonal sub-block.  Lane i owns row i in registers; the
             // values every lane needs (pivot, column j) travel through a 32-float LDS line read back as
             // broadcasts -- an LDS round trip per column instead of ~500 v_readlane + hazard nops.
             const int i = lane & 31;
-            float a[32], x[32], invd[32];
+            float a[32], x[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) a[k] = Djj[i * LS + k];
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 float* col = colbuf + (j & 1) * 32;
-                if (lane < 32) col[i] = a[j];  // current column j (rows >= j are valid)
+                if (VARIANT == 0 || lane < 32) col[i] = a[j];  // current column j (rows >= j are valid)
                 float d = col[j];
                 asm volatile("" : "+v"(d));  // keep wave-uniform values in VGPRs (no SGPR spills / readlane traffic)
                 if (!(d > pivot_floor)) {
@@ -119,11 +127,14 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
                 }
                 float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, ~1 ulp: ample for a preconditioner
                 asm volatile("" : "+v"(inv));
-                invd[j] = inv;
                 const float lij = a[j] * inv;                // L[i][j] for i > j
                 a[j] = (i == j) ? d * inv : lij;
 #pragma unroll
-                for (int k = j + 1; k < 32; ++k) a[k] = fmaf(-lij, col[k] * inv, a[k]);  // a[i][k] -= L[i][j] L[k][j]
+                for (int k = j + 1; k < 32; ++k) {  // a[i][k] -= L[i][j] L[k][j]
+                    float ck = col[k];
+                    if (VARIANT == 0) asm volatile("" : "+v"(ck));  // stay in VGPRs: scalarising 496 broadcasts spills SGPRs
+                    a[k] = fmaf(-lij, ck * inv, a[k]);
+                }
             }
             if (lane < 32) {
 #pragma unroll
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
                 float sacc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < ii; ++k) sacc = fmaf(Djj[ii * LS + k], x[k], sacc);  // broadcast LDS reads
-                x[ii] = (((i == ii) ? 1.0f : 0.0f) - sacc) * invd[ii];
+                x[ii] = (((i == ii) ? 1.0f : 0.0f) - sacc) / Djj[ii * LS + ii];
             }
             if (lane < 32) {
 #pragma unroll
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
         if (!(dbg & 4)) {
             const int ib = jb + 1 + wave;
             if (ib < 4) {
-                float* Aij = Ls + (ib * 32) * LS + jb * 32;
+                float* Aij = Lb + blk(ib, jb) * BLK;
                 f32x16 acc = blk_mma<false>(Aij, Xjj, zero16(), 1.0f, lane);
                 blk_store(Aij, acc, lane);
             }
@@ -159,9 +170,9 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
             for (int ib = jb + 1; ib < 4; ++ib)
                 for (int kb = jb + 1; kb <= ib; ++kb, ++cnt) {
                     if ((cnt & 3) != wave) continue;
-                    float* Cik = Ls + (ib * 32) * LS + kb * 32;
+                    float* Cik = Lb + blk(ib, kb) * BLK;
                     f32x16 acc = blk_load(Cik, lane);
-                    acc = blk_mma<false>(Ls + (ib * 32) * LS + jb * 32, Ls + (kb * 32) * LS + jb * 32, acc, -1.0f, lane);
+                    acc = blk_mma<false>(Lb + blk(ib, jb) * BLK, Lb + blk(kb, jb) * BLK, acc, -1.0f, lane);
                     blk_store(Cik, acc, lane);
                 }
         }
@@ -169,40 +180,43 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
     }
 
     // ---- assemble the 128x128 inverse: X[ib][jb] = -Dinv_ii * sum_{k=jb}^{ib-1} L[ib][k] X[k][jb] ----
+#pragma unroll 1
     for (int dist = 1; dist < ((dbg & 2) ? 1 : 4); ++dist) {
         const int ib = dist + wave, jb = wave;  // wave w owns block (dist + w, w)
         const bool active = ib < 4;
-        float* scratch = Xs + (jb * 32) * LS + ib * 32;  // the (zero) upper block (jb, ib), valid when active
+        float* scratch = Tb + (wave < 3 ? wave : 0) * BLK;
         if (active) {
             f32x16 t = zero16();
             for (int k = jb; k < ib; ++k)
-                t = blk_mma<true>(Ls + (ib * 32) * LS + k * 32, Xs + (k * 32) * LS + jb * 32, t, 1.0f, lane);
+                t = blk_mma<true>(Lb + blk(ib, k) * BLK, Xb + blk(k, jb) * BLK, t, 1.0f, lane);
             blk_store(scratch, t, lane);
         }
         __syncthreads();
-        f32x16 xr = zero16();
-        if (active) xr = blk_mma<true>(Xs + (ib * 32) * LS + ib * 32, scratch, zero16(), -1.0f, lane);
-        __syncthreads();
         if (active) {
-            blk_store(Xs + (ib * 32) * LS + jb * 32, xr, lane);
-            blk_store(scratch, zero16(), lane);
+            f32x16 xr = blk_mma<true>(Xb + blk(ib, ib) * BLK, scratch, zero16(), -1.0f, lane);
+            blk_store(Xb + blk(ib, jb) * BLK, xr, lane);
         }
         __syncthreads();
     }
 
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int idx = (tid + 256 * e) * 4;
-        const int r = idx >> 7, c = idx & 127;
-        const float* lp = Ls + r * LS + c;
-        const float* xp = Xs + r * LS + c;
-        if (c + 3 <= r) {
-            *reinterpret_cast<float4*>(A + (int64_t)r * ld + c) = make_float4(lp[0], lp[1], lp[2], lp[3]);
-        } else if (c <= r) {  // the 4-wide group straddles the diagonal: keep the caller's upper entries
-            for (int k = 0; k < 4; ++k)
-                if (c + k <= r) A[(int64_t)r * ld + c + k] = lp[k];
+    // ---- write back: L into the lower triangle of A, X (with its zero upper blocks) into dinv ----
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+        const int ib = b >> 2, jb = b & 3;
+        float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jb <= ib) {
+            const float* lp = Lb + blk(ib, jb) * BLK + lr * LS + lc;
+            const float* xp = Xb + blk(ib, jb) * BLK + lr * LS + lc;
+            xo = make_float4(xp[0], xp[1], xp[2], xp[3]);
+            float* ap = A + (int64_t)(ib * 32 + lr) * ld + jb * 32 + lc;
+            if (ib != jb || lc + 3 <= lr) {
+                *reinterpret_cast<float4*>(ap) = make_float4(lp[0], lp[1], lp[2], lp[3]);
+            } else {  // the 4-wide group straddles or lies above the diagonal: keep the caller's upper entries
+                for (int k = 0; k < 4; ++k)
+                    if (lc + k <= lr) ap[k] = lp[k];
+            }
         }
-        *reinterpret_cast<float4*>(dinv + idx) = make_float4(xp[0], xp[1], xp[2], xp[3]);
+        *reinterpret_cast<float4*>(dinv + (ib * 32 + lr) * 128 + jb * 32 + lc) = xo;
     }
     if (wave == 0 && lane == 0 && nclamp > 0 && clamped != nullptr) atomicAdd(clamped, nclamp);
 }
@@ -210,7 +224,10 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
 }  // namespace
 
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s) {
-    hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, g_debug[0]);
+    if (g_debug[3] != 1)  // variant 1 (scalarised broadcasts) measured 57 us vs 84 us for variant 0
+        hipLaunchKernelGGL(k_potrf_leaf<1>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, g_debug[0]);
+    else
+        hipLaunchKernelGGL(k_potrf_leaf<0>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, g_debug[0]);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -254,6 +271,125 @@ static int potrf_rec(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clam
     NNGP_TRY(trsm_rlt_f32(a21, ld, n2, a, ld, dinv, n1, s));
     NNGP_TRY(launch_gemm_nt_f32(a22, ld, a21, ld, a21, ld, n2, n2, n1, -1.0f, 1.0f, true, s));
     return potrf_rec(a22, n2, ld, dinv + (n1 / TB) * TB * TB, clamped, pivot_floor, s);
+}
+
+// ---- look-ahead driver -----------------------------------------------------------------------------------
+// The recursion above runs ~2300 dependent launches; about a third of its wall time is spent in kernels too small
+// to fill 256 CUs (leaves, 128-wide triangular solves).  The look-ahead form cuts the matrix into block columns of
+// width nb and uses two HIP streams: the high-priority "panel" stream factors block column k+1 (small kernels) while
+// the low-priority "update" stream applies block column k to the rest of the trailing matrix (large SYRKs), so the
+// small kernels run in the shadow of the large ones instead of in sequence with them.
+//   panel  : wait col[k-1]; potrf(A_kk) (recursive chain of small kernels); record panel[k]
+//   update : wait panel[k]; trsm(rows below); update diagonal block k+1 first; record col[k]; update the rest
+int lookahead_create(LookAhead** out) {
+    LookAhead* la = new (std::nothrow) LookAhead();
+    NNGP_REQUIRE(la != nullptr, "lookahead_create: out of memory");
+    // Optional CU partition (timing experiment, NNGP debug key 5 = 2): the panel stream owns `panel_cus` compute units,
+    // the update stream the rest.  Measured at N = 32768: 138.6 ms (32 CUs) / 202 ms (16) / 140 ms (64) against 124.2 ms
+    // for plain priority streams and 126.1 ms for the single-stream recursion -- so the default is priority streams.
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    const int panel_cus = g_debug[4] > 0 ? g_debug[4] : 32;
+    bool masked = false;
+    if (g_debug[5] == 2 && ncu >= 64 && panel_cus < ncu) {
+        const int words = (ncu + 31) / 32;
+        uint32_t mp[16] = {0}, mu[16] = {0};
+        // spread the panel CUs evenly over the device (every (ncu / panel_cus)-th CU) so that each XCD keeps most of its CUs
+        const int stride = ncu / panel_cus;
+        for (int c = 0; c < ncu; ++c) {
+            const bool is_panel = (c % stride == 0) && (c / stride < panel_cus);
+            (is_panel ? mp : mu)[c / 32] |= (1u << (c % 32));
+        }
+        if (words <= 16 && hipExtStreamCreateWithCUMask(&la->panel, words, mp) == hipSuccess) {
+            if (hipExtStreamCreateWithCUMask(&la->update, words, mu) == hipSuccess) {
+                masked = true;
+            } else {
+                (void)hipStreamDestroy(la->panel);
+                la->panel = nullptr;
+            }
+        }
+    }
+    la->masked = masked;
+    if (!masked) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        if (hipStreamCreateWithPriority(&la->panel, hipStreamNonBlocking, greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&la->update, hipStreamNonBlocking, least) != hipSuccess) {
+            set_error("lookahead_create: hipStreamCreateWithPriority failed");
+            delete la;
+            return -1;
+        }
+    }
+    hipEvent_t* all[3] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done};
+    for (auto e : all)
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
+    for (int i = 0; i < LookAhead::kMaxSteps; ++i)
+        if (hipEventCreateWithFlags(&la->ev_panel[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&la->ev_col[i], hipEventDisableTiming) != hipSuccess) {
+            set_error("hipEventCreate failed");
+            return -1;
+        }
+    *out = la;
+    return 0;
+}
+
+void lookahead_destroy(LookAhead* la) {
+    if (!la) return;
+    (void)hipStreamSynchronize(la->panel);
+    (void)hipStreamSynchronize(la->update);
+    (void)hipStreamDestroy(la->panel);
+    (void)hipStreamDestroy(la->update);
+    (void)hipEventDestroy(la->ev_in); (void)hipEventDestroy(la->ev_panel_done); (void)hipEventDestroy(la->ev_update_done);
+    for (int i = 0; i < LookAhead::kMaxSteps; ++i) { (void)hipEventDestroy(la->ev_panel[i]); (void)hipEventDestroy(la->ev_col[i]); }
+    delete la;
+}
+
+int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
+                        LookAhead* la, hipStream_t user) {
+    NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
+    int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : (n >= 24576 ? 4096 : (n >= 12288 ? 2048 : 1024));
+    nb = (nb / TB) * TB;
+    if (la == nullptr || g_debug[2] != 0 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
+        return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_in, 0));
+    int rc = 0;
+    int k = 0;
+    for (int64_t o = 0; o < n && rc == 0; o += nb, ++k) {
+        const int64_t nbk = (n - o < nb) ? n - o : nb;
+        const int64_t m = n - o - nbk;  // rows below this block column
+        float* akk = a + o * ld + o;
+        float* dk = dinv + (o / TB) * TB * TB;
+        // panel stream: factor the diagonal block (chain of small kernels)
+        if (k > 0) NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_col[k - 1], 0));
+        rc = potrf_rec(akk, nbk, ld, dk, clamped, pivot_floor, la->panel);
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_panel[k], la->panel));
+        if (rc != 0 || m == 0) break;
+        // update stream: triangular solve of the rows below, then the trailing update
+        NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_panel[k], 0));
+        rc = trsm_rlt_f32(akk + nbk * ld, ld, m, akk, ld, dk, nbk, la->update);
+        const int64_t nb2 = (m < nb) ? m : nb;
+        const float* p = akk + nbk * ld;        // panel rows below the diagonal block: [m, nbk]
+        float* c = akk + nbk * ld + nbk;        // trailing matrix: [m, m]
+        // next diagonal block first (the panel stream is waiting for it) ...
+        if (rc == 0) rc = launch_gemm_nt_f32(c, ld, p, ld, p, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, la->update);
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_col[k], la->update));
+        // ... then the rest of the trailing matrix, overlapped with the factorisation of the next diagonal block
+        if (rc == 0 && m > nb2) {
+            rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
+            if (rc == 0)
+                rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, nbk,
+                                        -1.0f, 1.0f, true, la->update);
+        }
+    }
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, la->panel));
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, la->update));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_panel_done, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_update_done, 0));
+    return rc;
 }
 
 int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s) {

@@ -52,7 +52,15 @@ def allgather_rows(buf, n: int, group=None):
         raise ValueError("all-gather buffer has %d rows, needs %d" % (buf.shape[0], world * c))
     mine = buf[r * c:(r + 1) * c].contiguous().clone()
     out = buf[: world * c]
-    if out.is_contiguous():
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        # rehearsal path (gloo with device buffers): stage through the host, chunk by chunk to bound host memory
+        host = mine.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        for g, p in enumerate(parts):
+            if g != r:
+                out[g * c:(g + 1) * c].copy_(p)
+    elif out.is_contiguous():
         dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
     else:  # pragma: no cover
         parts = [torch.empty_like(mine) for _ in range(world)]

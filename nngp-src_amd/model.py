@@ -69,8 +69,8 @@ class GPModel:
         _lib.check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 
     def set_refine(self, sweeps: int):
-        """Precision level of the posterior covariance: 0 = float32 solve only; 1 = one float64 correction sweep
-        (default); L >= 2 = L-1 sweeps plus the second-order formula."""
+        """Precision level of the posterior covariance: 0 = float32 solve only; 1 = one float64 correction sweep;
+        L >= 2 = L-1 sweeps plus the second-order formula (default 2)."""
         _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 

@@ -63,11 +63,14 @@ def main():
     base = torch.randn((128, 128), device=dev)
     spd = base @ base.T / 128 + torch.eye(128, device=dev) * 2.0
     a = spd.clone(); dinv = torch.empty((1, 128, 128), device=dev); clamped = torch.zeros(1, dtype=torch.int32, device=dev)
-    for dbg in (0, 1, 2, 4, 7):
-        lib.nngp_debug_set(0, dbg)
-        ms = timeit(lambda: _lib.check(lib.nngp_potrf_f32(_lib.ptr(a), 128, 128, _lib.ptr(dinv), _lib.ptr(clamped), _lib.stream_ptr())), reps=50)
-        out["leaf_dbg%d_us" % dbg] = round(ms * 1e3, 2)
+    for variant in (0, 1):
+        lib.nngp_debug_set(3, variant)
+        for dbg in (0, 1, 2, 4, 7):
+            lib.nngp_debug_set(0, dbg)
+            ms = timeit(lambda: _lib.check(lib.nngp_potrf_f32(_lib.ptr(a), 128, 128, _lib.ptr(dinv), _lib.ptr(clamped), _lib.stream_ptr())), reps=50)
+            out["leaf_v%d_dbg%d_us" % (variant, dbg)] = round(ms * 1e3, 2)
     lib.nngp_debug_set(0, 0)
+    lib.nngp_debug_set(3, 0)
     print(json.dumps(out, indent=1))
 
 

@@ -275,7 +275,7 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     prior = o.diag_kernel(np.sum(xt * xt, axis=1) / d, o.make_arch(n_relu))[0]
     assert np.abs(var32 - np.diag(cov_ref)).max() < 1e-4 * prior.max()
     assert np.abs(cov32 - cov_ref).max() < 1e-4 * prior.max()
-    model.set_refine(1)
+    model.set_refine(2)
     assert np.array_equal(model.predict(xt, cov=False), mean)
     # x_test=None: predictions on the training rows (estimator.py:37-40)
     mean_tr, var_tr = model.predict(None, cov="diag")
@@ -367,3 +367,27 @@ def test_large_size_properties():
     np.testing.assert_allclose(mean_tr, y - info["reg"] * alpha, atol=1e-7 * np.abs(y).max())  # K alpha = y - reg alpha
     model2 = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, 3.0 * y)
     assert G.rel_l2(model2.alpha().cpu().numpy(), 3.0 * alpha) < 1e-8
+
+
+def test_lookahead_cholesky_matches_recursion():
+    """N=8192 takes the two-stream look-ahead driver (block columns of 1024); it must agree with the recursion bit for bit
+    on the factor (same kernels, same per-tile arithmetic order) and with the oracle rows on alpha."""
+    from nngp_src_amd import _lib
+    n, d = 8192, 32
+    x, y = synth.synthetic_queries(n, d, seed=5)
+    a = o.make_arch(1)
+    lib = _lib.load()
+    alphas = []
+    for disable in (0, 1):
+        lib.nngp_debug_set(2, disable)
+        model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
+        info = model.info()
+        assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+        alphas.append(model.alpha().cpu().numpy())
+        model.close()
+    lib.nngp_debug_set(2, 0)
+    assert G.rel_l2(alphas[0], alphas[1]) < 1e-9
+    rows = np.arange(0, n, 511)
+    Krows = o.kernel_fn(x[rows], x, "nngp", a)
+    reg = 1e-3 * np.mean(np.sum(x * x, axis=1) / d / 2)
+    assert np.abs(Krows @ alphas[0] + reg * alphas[0][rows] - y[rows]).max() < 1e-7 * np.abs(y).max()
