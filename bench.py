@@ -128,7 +128,10 @@ def main():
             buf, _ = model.kernel_buffer(all_rows=True)
             distributed.allgather_rows(buf, n)
         e3 = ev()
-        model.factor()
+        if world > 1 and os.environ.get("NNGP_DIST_CHOL", "1") != "0":
+            distributed.distributed_factor(model)  # block columns dealt cyclically, one broadcast per column
+        else:
+            model.factor()
         e4 = ev()
         model.solve()
         e5 = ev()
@@ -178,7 +181,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": m,
-                       "parallelism": "row-block kernel shard x%d + all-gather, replicated Cholesky" % world if world > 1 else "single GPU",
+                       "parallelism": ("row-block kernel shard x%d + all-gather, block-cyclic Cholesky (broadcast per block column), "
+                                       "replicated solve, test rows sharded" % world) if world > 1 else "single GPU",
                        "precision": "float64 kernel build + CG residual, float32 MFMA Cholesky (preconditioner), float64 means"},
             "roofline": {"bound": "mfma", "achieved": round(chol_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(chol_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

@@ -102,6 +102,19 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
 int nngp_model_factor(nngp_model* m, void* stream);
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream);
 
+/* Block-column pieces of `factor` for the multi-GPU right-looking Cholesky (host: nngp-src_amd/distributed.py):
+ * block columns of width w (multiple of 128) are dealt cyclically to the ranks; the owner factors its column
+ * (factor_panel: Cholesky of the diagonal block + triangular solve of the rows below), the column travels by RCCL
+ * broadcast into every rank's copy of the factor buffer, and each rank applies it to the block columns it owns
+ * (factor_update).  factor == factor_begin + [single-GPU recursion] + factor_end. */
+int nngp_model_factor_begin(nngp_model* m, void* stream);
+int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* stream);
+int nngp_model_factor_update(nngp_model* m, int64_t panel_col0, int64_t panel_width, int64_t col0, int64_t width,
+                             void* stream);
+int nngp_model_factor_end(nngp_model* m, void* stream);
+/* float32 factor buffer [n_padded, ld] (lower triangle) and the inverted 128-blocks [n_padded/128][128*128]. */
+int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv);
+
 /* The float64 train-train kernel buffer (device pointer, leading dimension in elements) so the host
  * can all-gather row blocks over RCCL between build_rows and factor. */
 int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld);

@@ -22,7 +22,8 @@ MAX_DENSE = 16
 ABI_SYMBOLS = (
     "nngp_version", "nngp_debug_set", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
-    "nngp_model_factor", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
+    "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
+    "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32",
 )
@@ -69,6 +70,11 @@ def load():
     lib.nngp_model_set_train.argtypes = [vp, vp, vp, i64, vp]
     lib.nngp_model_build_rows.argtypes = [vp, i64, i64, vp]
     lib.nngp_model_factor.argtypes = [vp, vp]
+    lib.nngp_model_factor_begin.argtypes = [vp, vp]
+    lib.nngp_model_factor_panel.argtypes = [vp, i64, i64, vp]
+    lib.nngp_model_factor_update.argtypes = [vp, i64, i64, i64, i64, vp]
+    lib.nngp_model_factor_end.argtypes = [vp, vp]
+    lib.nngp_model_factor_buffers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(vp)]
     lib.nngp_model_solve.argtypes = [vp, i32, dbl, vp]
     lib.nngp_model_kernel_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     lib.nngp_model_info.argtypes = [vp, ctypes.POINTER(NngpFitInfo)]

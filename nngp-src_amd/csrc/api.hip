@@ -395,13 +395,31 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     return 0;
 }
 
-int nngp_model_factor(nngp_model* m, void* stream) {
+int nngp_model_factor_begin(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
     NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
+    m->factored = m->solved = false;
+    return 0;
+}
+
+int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* stream) {
+    NNGP_REQUIRE(m != nullptr && m->built, "factor_panel: build the kernel rows first");
     // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
-    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, s));
+    return potrf_panel_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), col0, width,
+                           (hipStream_t)stream);
+}
+
+int nngp_model_factor_update(nngp_model* m, int64_t panel_col0, int64_t panel_width, int64_t col0, int64_t width,
+                             void* stream) {
+    NNGP_REQUIRE(m != nullptr && m->built, "factor_update: build the kernel rows first");
+    return potrf_update_f32(m->a32, m->np, m->np, panel_col0, panel_width, col0, width, (hipStream_t)stream);
+}
+
+int nngp_model_factor_end(nngp_model* m, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->built, "factor_end: build the kernel rows first");
     m->tri.bs = triinv_block(m->np);
     NNGP_TRY(triinv_build(m->a32, m->np, m->dinv, m->np, m->tri, s));
     m->factored = true;
@@ -409,6 +427,21 @@ int nngp_model_factor(nngp_model* m, void* stream) {
     m->lt_ready = false;
     m->aux_ready = false;
     return 0;
+}
+
+int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv) {
+    NNGP_REQUIRE(m != nullptr && m->have_train, "factor_buffers: call set_train first");
+    if (a32) *a32 = m->a32;
+    if (ld) *ld = m->np;
+    if (dinv) *dinv = m->dinv;
+    return 0;
+}
+
+int nngp_model_factor(nngp_model* m, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_TRY(nngp_model_factor_begin(m, stream));
+    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, s));
+    return nngp_model_factor_end(m, stream);
 }
 
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {

@@ -96,6 +96,9 @@ int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
                         LookAhead* la, hipStream_t user);
+int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
+                    int64_t w, hipStream_t s);
+int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s);
 int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
                  hipStream_t s);
 

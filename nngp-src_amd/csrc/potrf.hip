@@ -392,6 +392,33 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     return rc;
 }
 
+// ---- block-column pieces of the right-looking factorisation (multi-GPU: block columns are dealt cyclically) ----
+// Factor block column [o, o+w): Cholesky of the diagonal block, then the rows below times its inverse transpose.
+int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
+                    int64_t w, hipStream_t s) {
+    NNGP_REQUIRE(o >= 0 && w > 0 && o + w <= n && o % TB == 0 && w % TB == 0, "potrf_panel: bad block column");
+    float* akk = a + o * ld + o;
+    float* dk = dinv + (o / TB) * TB * TB;
+    NNGP_TRY(potrf_rec(akk, w, ld, dk, clamped, pivot_floor, s));
+    const int64_t m = n - o - w;
+    if (m > 0) NNGP_TRY(trsm_rlt_f32(akk + w * ld, ld, m, akk, ld, dk, w, s));
+    return 0;
+}
+
+// Apply the finished block column [po, po+pw) to block column [o, o+w), o >= po + pw:
+//   A[o:, o:o+w] -= L[o:, po:po+pw] L[o:o+w, po:po+pw]^T   (lower part of the diagonal block only)
+int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s) {
+    NNGP_REQUIRE(po >= 0 && pw > 0 && o >= po + pw && w > 0 && o + w <= n && o % TB == 0 && w % TB == 0 && po % TB == 0 &&
+                     pw % TB == 0, "potrf_update: bad block columns");
+    const float* p = a + o * ld + po;   // panel rows [o, n), columns [po, po+pw)
+    float* c = a + o * ld + o;
+    NNGP_TRY(launch_gemm_nt_f32(c, ld, p, ld, p, ld, w, w, pw, -1.0f, 1.0f, true, s));
+    const int64_t below = n - o - w;
+    if (below > 0)
+        NNGP_TRY(launch_gemm_nt_f32(c + w * ld, ld, p + w * ld, ld, p, ld, below, w, pw, -1.0f, 1.0f, false, s));
+    return 0;
+}
+
 int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s) {
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
     NNGP_REQUIRE(ld >= n && ld % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)dinv & 15) == 0,

@@ -92,7 +92,101 @@ def sharded_kernel(kernel_fn, x1, x2=None, get="nngp", group=None):
     return buf[:n1].cpu().numpy()
 
 
-def sharded_fit(model, x, y, group=None, timings=None):
+def panel_width(np_: int) -> int:
+    """Block-column width of the distributed Cholesky (multiple of 128)."""
+    return 1024 if np_ >= 8192 else (512 if np_ >= 2048 else 128)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _broadcast(t, src, group=None, async_op=False):
+    """Broadcast a contiguous device tensor and return a handle with .wait().  nccl (= RCCL): asynchronous on the
+    communicator's stream; gloo rehearsals stage through the host synchronously."""
+    dist = _dist()
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        if rank() != src:
+            t.copy_(h)
+        return _Done()
+    work = dist.broadcast(t, src=src, group=group, async_op=async_op)
+    return work if async_op else _Done()
+
+
+def distributed_factor(model, group=None, nb: int = None):
+    """Right-looking float32 Cholesky with the block columns dealt cyclically to the ranks (SURVEY.md 8f row N4, 1-D form).
+
+    Every rank keeps a full copy of the factor buffer.  Block column k is final on its owner (k mod world) once the
+    owner has applied columns < k to it; the owner factors it (diagonal block + rows below) and broadcasts it together
+    with its inverted 128-blocks (one RCCL broadcast of (n - o) * w + w * 128 floats); every rank stores it in place
+    and applies it to the block columns it owns.  Each rank therefore does 1/world of the O(N^3) trailing updates and
+    ends with the complete factor -- the replicated triangular solves that follow need no further exchange.
+
+    Look-ahead: after receiving column k, the owner of column k+1 updates and factors THAT column first and starts
+    its broadcast; all ranks post the (asynchronous) receive before applying column k to the rest of their columns,
+    so the transfer of column k+1 over xGMI overlaps with the trailing updates of column k.
+    """
+    import torch
+    world, r = world_size(), rank()
+    model.factor_begin()
+    a32, dinv = model.factor_buffers()
+    np_ = a32.shape[0]
+    w = nb or panel_width(np_)
+    ncols = (np_ + w - 1) // w
+    owned = [j for j in range(ncols) if j % world == r]
+    width = lambda j: min(w, np_ - j * w)
+    stages = [torch.empty(((np_ * w) + w * 128,), dtype=torch.float32, device=a32.device) for _ in range(2)] if world > 1 else None
+
+    def views(k):
+        o, wk = k * w, width(k)
+        rows = np_ - o
+        buf = stages[k & 1][: rows * wk + wk * 128]
+        return o, wk, buf[: rows * wk].view(rows, wk), buf[rows * wk:].view(wk // 128, 128, 128), buf
+
+    def factor_and_send(k):
+        """Owner: factor block column k and pack it; everyone: post the broadcast.  Returns the handle."""
+        o, wk, pan, inv, buf = views(k)
+        if k % world == r:
+            model.factor_panel(o, wk)
+            pan.copy_(a32[o:, o:o + wk])
+            inv.copy_(dinv[o // 128:(o + wk) // 128])
+        return _broadcast(buf, k % world, group, async_op=True)
+
+    def receive(k, handle):
+        handle.wait()
+        if k % world != r:
+            o, wk, pan, inv, _ = views(k)
+            a32[o:, o:o + wk].copy_(pan)
+            dinv[o // 128:(o + wk) // 128].copy_(inv)
+
+    if world == 1:
+        for k in range(ncols):
+            model.factor_panel(k * w, width(k))
+            for j in range(k + 1, ncols):
+                model.factor_update(k * w, width(k), j * w, width(j))
+        model.factor_end()
+        return model
+
+    handle = factor_and_send(0)
+    for k in range(ncols):
+        receive(k, handle)
+        o, wk = k * w, width(k)
+        nxt = k + 1
+        if nxt < ncols:
+            if nxt % world == r:
+                model.factor_update(o, wk, nxt * w, width(nxt))  # column k+1 first: it is on the critical path
+            handle = factor_and_send(nxt)
+        for j in owned:
+            if j > nxt:
+                model.factor_update(o, wk, j * w, width(j))
+    model.factor_end()
+    return model
+
+
+def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True):
     """GPModel fit with the kernel build sharded over ranks: build own rows -> all-gather -> replicated
     factor + solve.  The model must have been created with n_cap >= world * ceil(n / world)."""
     import torch
@@ -111,7 +205,10 @@ def sharded_fit(model, x, y, group=None, timings=None):
         buf, _ = model.kernel_buffer(all_rows=True)
         allgather_rows(buf, n, group)
     t2 = ev()
-    model.factor()
+    if world > 1 and distributed_cholesky:
+        distributed_factor(model, group)
+    else:
+        model.factor()
     t3 = ev()
     model.solve()
     t4 = ev()

@@ -65,6 +65,29 @@ class GPModel:
     def factor(self):
         _lib.check(self.lib.nngp_model_factor(self.handle, _lib.stream_ptr()))
 
+    # block-column pieces of factor() for the multi-GPU Cholesky (distributed.distributed_factor)
+    def factor_begin(self):
+        _lib.check(self.lib.nngp_model_factor_begin(self.handle, _lib.stream_ptr()))
+
+    def factor_panel(self, col0: int, width: int):
+        _lib.check(self.lib.nngp_model_factor_panel(self.handle, int(col0), int(width), _lib.stream_ptr()))
+
+    def factor_update(self, panel_col0: int, panel_width: int, col0: int, width: int):
+        _lib.check(self.lib.nngp_model_factor_update(self.handle, int(panel_col0), int(panel_width), int(col0), int(width),
+                                                     _lib.stream_ptr()))
+
+    def factor_end(self):
+        _lib.check(self.lib.nngp_model_factor_end(self.handle, _lib.stream_ptr()))
+
+    def factor_buffers(self):
+        """(a32 [np, np] float32 view, dinv [np/128, 128, 128] float32 view) of the library-owned factor buffers."""
+        a, ld, d = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p()
+        _lib.check(self.lib.nngp_model_factor_buffers(self.handle, ctypes.byref(a), ctypes.byref(ld), ctypes.byref(d)))
+        np_ = ld.value
+        a32 = _wrap_device(a.value, np_ * np_, self.device, "<f4").view(np_, np_)
+        dinv = _wrap_device(d.value, (np_ // 128) * 128 * 128, self.device, "<f4").view(np_ // 128, 128, 128)
+        return a32, dinv
+
     def solve(self, max_iters: int = 0, tol: float = 0.0):
         _lib.check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 
@@ -88,7 +111,7 @@ class GPModel:
         _lib.check(self.lib.nngp_model_kernel_buffer(self.handle, ctypes.byref(p), ctypes.byref(ld)))
         np_cap = (self.n_cap + 127) // 128 * 128
         rows = (np_cap * np_cap) // ld.value if all_rows else self.n
-        return _wrap_device_f64(p.value, rows * ld.value, self.device).view(rows, ld.value), ld.value
+        return _wrap_device(p.value, rows * ld.value, self.device, "<f8").view(rows, ld.value), ld.value
 
     def info(self) -> dict:
         fi = _lib.NngpFitInfo()
@@ -128,14 +151,14 @@ class GPModel:
         return mean if out is None else (mean, out)
 
 
-def _wrap_device_f64(address: int, count: int, device):
-    """Zero-copy torch view of library-owned HBM (float64)."""
+def _wrap_device(address: int, count: int, device, typestr: str):
+    """Zero-copy torch view of library-owned HBM (typestr '<f8' or '<f4')."""
     import torch
 
     class _Holder:
         pass
 
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (address, False), "version": 3,
+    h.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (address, False), "version": 3,
                                   "strides": None}
     return torch.as_tensor(h, device=device)

@@ -391,3 +391,25 @@ def test_lookahead_cholesky_matches_recursion():
     Krows = o.kernel_fn(x[rows], x, "nngp", a)
     reg = 1e-3 * np.mean(np.sum(x * x, axis=1) / d / 2)
     assert np.abs(Krows @ alphas[0] + reg * alphas[0][rows] - y[rows]).max() < 1e-7 * np.abs(y).max()
+
+
+def test_right_looking_block_columns_single_rank():
+    """The block-column pieces (factor_panel / factor_update) that the multi-GPU Cholesky deals out, run on one rank."""
+    from nngp_src_amd import distributed
+    n, d = 3000, 32
+    x, y = synth.synthetic_queries(n, d, seed=7)
+    a = o.make_arch(1)
+    ref = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
+    model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3)
+    model.set_train(x, y)
+    model.build_rows(0, n)
+    distributed.distributed_factor(model, nb=512)
+    model.solve()
+    info = model.info()
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+    assert G.rel_l2(model.alpha().cpu().numpy(), ref.alpha().cpu().numpy()) < 1e-9
+    xt, _ = synth.synthetic_queries(40, d, seed=8)
+    m1, v1 = model.predict(xt, cov="diag")
+    m0, v0 = ref.predict(xt, cov="diag")
+    assert G.mean_gate(m1, m0)[0] < 1e-9
+    np.testing.assert_allclose(v1, v0, rtol=1e-6)
