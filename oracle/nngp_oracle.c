@@ -192,42 +192,49 @@ int oracle_potrf_lower(double* a, int64_t n, int64_t ld) {
     return info;
 }
 
-/* solve L L^T X = B in place; B is n x nrhs row-major (ldb), L lower n x n (ld). */
-void oracle_potrs_lower(const double* l, int64_t n, int64_t ld, double* bm, int64_t nrhs,
-                        int64_t ldb) {
+/* Row-oriented substitution, vectorised over the right-hand sides (contiguous in memory) and parallel over
+ * column chunks; B is n x nrhs row-major (ldb), L lower n x n (ld).                                      */
+#define RHS_CHUNK 32
+static void forward_lower(const double* l, int64_t n, int64_t ld, double* bm, int64_t nrhs, int64_t ldb) {
 #pragma omp parallel for schedule(static)
-    for (int64_t c0 = 0; c0 < nrhs; c0 += 8) {
-        const int64_t c1 = c0 + 8 < nrhs ? c0 + 8 : nrhs;
+    for (int64_t c0 = 0; c0 < nrhs; c0 += RHS_CHUNK) {
+        const int64_t w = c0 + RHS_CHUNK < nrhs ? RHS_CHUNK : nrhs - c0;
         for (int64_t i = 0; i < n; ++i) {
-            for (int64_t c = c0; c < c1; ++c) {
-                double s = bm[i * ldb + c];
-                for (int64_t k = 0; k < i; ++k) s -= l[i * ld + k] * bm[k * ldb + c];
-                bm[i * ldb + c] = s / l[i * ld + i];
+            double* bi = bm + i * ldb + c0;
+            for (int64_t k = 0; k < i; ++k) {
+                const double lik = l[i * ld + k];
+                const double* bk = bm + k * ldb + c0;
+#pragma omp simd
+                for (int64_t c = 0; c < w; ++c) bi[c] -= lik * bk[c];
             }
+            const double inv = 1.0 / l[i * ld + i];
+            for (int64_t c = 0; c < w; ++c) bi[c] *= inv;
         }
+    }
+}
+
+static void backward_lower_t(const double* l, int64_t n, int64_t ld, double* bm, int64_t nrhs, int64_t ldb) {
+#pragma omp parallel for schedule(static)
+    for (int64_t c0 = 0; c0 < nrhs; c0 += RHS_CHUNK) {
+        const int64_t w = c0 + RHS_CHUNK < nrhs ? RHS_CHUNK : nrhs - c0;
         for (int64_t i = n - 1; i >= 0; --i) {
-            for (int64_t c = c0; c < c1; ++c) {
-                double s = bm[i * ldb + c] / l[i * ld + i];
-                bm[i * ldb + c] = s;
-                for (int64_t k = 0; k < i; ++k) bm[k * ldb + c] -= l[i * ld + k] * s;
+            double* bi = bm + i * ldb + c0;
+            const double inv = 1.0 / l[i * ld + i];
+            for (int64_t c = 0; c < w; ++c) bi[c] *= inv;
+            for (int64_t k = 0; k < i; ++k) {  /* b[k] -= L[i][k] x[i] */
+                const double lik = l[i * ld + k];
+                double* bk = bm + k * ldb + c0;
+#pragma omp simd
+                for (int64_t c = 0; c < w; ++c) bk[c] -= lik * bi[c];
             }
         }
     }
 }
 
-/* forward solve only: V = L^-1 B, B is n x nrhs row-major */
-static void forward_lower(const double* l, int64_t n, int64_t ld, double* bm, int64_t nrhs,
-                          int64_t ldb) {
-#pragma omp parallel for schedule(static)
-    for (int64_t c0 = 0; c0 < nrhs; c0 += 8) {
-        const int64_t c1 = c0 + 8 < nrhs ? c0 + 8 : nrhs;
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t c = c0; c < c1; ++c) {
-                double s = bm[i * ldb + c];
-                for (int64_t k = 0; k < i; ++k) s -= l[i * ld + k] * bm[k * ldb + c];
-                bm[i * ldb + c] = s / l[i * ld + i];
-            }
-    }
+/* solve L L^T X = B in place */
+void oracle_potrs_lower(const double* l, int64_t n, int64_t ld, double* bm, int64_t nrhs, int64_t ldb) {
+    forward_lower(l, n, ld, bm, nrhs, ldb);
+    backward_lower_t(l, n, ld, bm, nrhs, ldb);
 }
 
 /* fit: builds K (get = 1 nngp | 2 ntk), A = K + reg I, L = chol(A) (in l_out, n x n), alpha.

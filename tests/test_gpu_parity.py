@@ -413,3 +413,40 @@ def test_right_looking_block_columns_single_rank():
     m0, v0 = ref.predict(xt, cov="diag")
     assert G.mean_gate(m1, m0)[0] < 1e-9
     np.testing.assert_allclose(v1, v0, rtol=1e-6)
+
+
+def test_full_forest_run_against_c_oracle(golden_dir):
+    """The reference's own forest run at full size (train.py defaults: 18 000 queries, seed-10 split -> N=10 800 train,
+    M=3 600 test, d=20): posterior means, variances and the q-error profile against the float64 C oracle."""
+    from nngp_src_amd import encoder as enc, util
+    import contextlib, io
+    g = np.load(os.path.join(golden_dir, "forest_queries.npz"))
+    bounds, cards = g["bounds"], g["cards"]
+    sent = np.iinfo(np.int32).min
+    loader = enc.GeneralQueryEncoder()
+    lo, hi = g["col_lo"], g["col_hi"]
+    X = np.tile(np.array([0.0, 1000.0]), (bounds.shape[0], 10))
+    active = bounds[:, :, 0] != sent
+    scaled = (bounds.astype(np.float64) - lo[None, :, None]) / (hi - lo)[None, :, None] * 1000.0
+    X[:, 0::2] = np.where(active, scaled[:, :, 0], 0.0)
+    X[:, 1::2] = np.where(active, scaled[:, :, 1], 1000.0)
+    q0 = [(c, float(bounds[0, c, 0]), float(bounds[0, c, 1])) for c in range(10) if active[0, c]]
+    np.testing.assert_array_equal(X[0], loader.transform_to_1d_array(q0))  # vectorised encoding == the encoder
+    Y = np.log2(cards.astype(np.float64))[:, None]
+    with contextlib.redirect_stdout(io.StringIO()):
+        Xtr, Ytr, _, Xte, Yte, _, _, _, _ = util.train_test_val_split(X, Y, 0.6, 0.2)
+    assert Xtr.shape == (10800, 20) and Xte.shape == (3600, 20)
+    a = o.make_arch(1)
+    ref = c_oracle.fit(Xtr, Ytr, a.w_std, a.b_std)
+    mean_ref, var_ref = c_oracle.predict_nngp(ref, Xte, 1)
+    model = GPModel(10800, 20, a.w_std, a.b_std, diag_reg=1e-3).fit(Xtr, Ytr)
+    info = model.info()
+    mean, var = model.predict(Xte, cov="diag")
+    l2, elem = G.mean_gate(mean, mean_ref)
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+    assert l2 < 1e-6 and elem < 1e-5, (l2, elem, info)
+    np.testing.assert_allclose(var, var_ref, rtol=1e-4)
+    pa, pb = util.q_error_profile((mean - Yte).ravel()), util.q_error_profile((mean_ref - Yte).ravel())
+    for key in pa:
+        assert abs(pa[key] - pb[key]) <= 1e-4 * abs(pb[key]), (key, pa[key], pb[key])
+    print("forest full run: cg_iters=%d, q-error median %.4f mean %.3f" % (info["refine_iters"], pa["median"], pa["mean"]))
