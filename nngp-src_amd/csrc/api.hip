@@ -80,6 +80,7 @@ struct nngp_model {
     double* tt_diag = nullptr;   // [m_cap] nngp K(x_t, x_t)
     double* ktd64 = nullptr;     // [m_cap, np_cap] float64 cross kernel
     float* b32 = nullptr;        // [mp_cap, np_cap] float32 RHS of the triangular solve
+    float* trsm_tmp = nullptr;   // [mp_cap, 1024] block-column scratch of the blocked triangular solves
     int64_t ktd_cap = 0;         // capacity (rows) of ktd64
     int64_t full_cap = 0;        // capacity (rows) of the full-covariance buffers
     double* ktt64 = nullptr;     // [full_cap, full_cap]
@@ -111,7 +112,7 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
-        dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(ktt64); dev_free(vvt32);
+        dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
 };
@@ -136,10 +137,11 @@ int ensure_predict_capacity(nngp_model* m, int64_t mt, bool need_ktd) {
     if (mt > m->m_cap || m->b32 == nullptr) {
         const int64_t cap = mt > m->m_cap ? mt : m->m_cap;
         NNGP_HIP_CHECK(hipDeviceSynchronize());
-        dev_free(m->xt_q); dev_free(m->tt_diag); dev_free(m->b32);
+        dev_free(m->xt_q); dev_free(m->tt_diag); dev_free(m->b32); dev_free(m->trsm_tmp);
         NNGP_TRY(dev_alloc(&m->xt_q, cap));
         NNGP_TRY(dev_alloc(&m->tt_diag, cap));
         NNGP_TRY(dev_alloc(&m->b32, round_up(cap, TB) * m->np_cap));
+        NNGP_TRY(dev_alloc(&m->trsm_tmp, round_up(cap, TB) * triinv_block(m->np_cap)));
         m->m_cap = cap;
     }
     if (need_ktd && mt > m->ktd_cap) {
@@ -193,8 +195,12 @@ int ensure_lt(nngp_model* m, hipStream_t s) {
 
 // b32 [mp, np] <- b32 (L L^T)^-1   (rows are right-hand sides)
 int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
-    NNGP_TRY(trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->np, m->dinv, m->np, s));
-    return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+    if (g_debug[7] == 1) {  // timing experiment: the 128-wide recursion instead of the 1024-block form
+        NNGP_TRY(trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->np, m->dinv, m->np, s));
+        return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+    }
+    NNGP_TRY(trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->np, m->tri, m->np, m->trsm_tmp, s));
+    return trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s);
 }
 
 // z64 <- rows of `rhs` [mp, np] times (K + reg I)^-1: float32 solves corrected by `sweeps` float64 residual sweeps.
@@ -549,7 +555,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     if (!is_ntk && m->var_refine == 0) {
         // float32 only: V^T = K_td L^-T, cov = K_tt - V^T V  (fast; error ~ cond * eps32 relative to the prior)
         NNGP_TRY(launch_convert_f64_f32(ktd, np, m->b32, np, mp, np, mp, np, s));
-        NNGP_TRY(trsm_rlt_f32(m->b32, np, mp, m->a32, np, m->dinv, np, s));
+        NNGP_TRY(trsm_rlt_blocks_f32(m->b32, np, mp, m->a32, np, m->tri, np, m->trsm_tmp, s));
         if (!full) return launch_row_sqsum_f32(m->b32, np, mt, np, m->tt_diag, var_or_cov, s);
         NNGP_TRY(build_ktt());
         NNGP_TRY(launch_gemm_nt_f32(m->vvt32, mp, m->b32, np, m->b32, np, mp, mp, np, 1.0f, 0.0f, false, s));

@@ -119,6 +119,10 @@ struct TriInv {
 };
 int64_t triinv_block(int64_t np);
 int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, hipStream_t s);
+int trsm_rlt_blocks_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
+                        float* tmp, hipStream_t s);
+int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
+                        float* tmp, hipStream_t s);
 // in-place solves L x = b / L^T x = b on a float32 vector of length np
 int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);
 int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);

@@ -207,6 +207,41 @@ int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriI
     return 0;
 }
 
+// B[m, np] <- B L^-T with the inverted bs-blocks: per block column J one GEMM with X_J = L_JJ^-1 (out of place into
+// `tmp`, [m, bs]) and one trailing GEMM -- 3 launches per block instead of the ~16 of the 128-wide recursion.
+int trsm_rlt_blocks_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
+                        float* tmp, hipStream_t s) {
+    const int64_t bs = ti.bs;
+    for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
+        const int64_t sz = (np - o < bs) ? np - o : bs;
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
+                                        hipMemcpyDeviceToDevice, s));
+        const int64_t rest = np - o - sz;
+        if (rest > 0)
+            NNGP_TRY(launch_gemm_nt_f32(b + o + sz, ldb, b + o, ldb, l + (o + sz) * ld + o, ld, m, rest, sz, -1.0f, 1.0f,
+                                        false, s));
+    }
+    return 0;
+}
+
+// B[m, np] <- B L^-1 = B U^-T with U = L^T stored in `lt`; block columns last to first, T_J = L_JJ^-T as the GEMM operand.
+int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
+                        float* tmp, hipStream_t s) {
+    const int64_t bs = ti.bs;
+    const int64_t nblk = (np + bs - 1) / bs;
+    for (int64_t j = nblk - 1; j >= 0; --j) {
+        const int64_t o = j * bs;
+        const int64_t sz = (np - o < bs) ? np - o : bs;
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
+                                        hipMemcpyDeviceToDevice, s));
+        if (o > 0)
+            NNGP_TRY(launch_gemm_nt_f32(b, ldb, b + o, ldb, lt + o, ld, m, o, sz, -1.0f, 1.0f, false, s));
+    }
+    return 0;
+}
+
 // Solves L x = b in place (b, length np, float32).  Block J: x_J = X_J b_J, then b[below] -= L[below, J] x_J.
 int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s) {
     const int64_t bs = ti.bs;
