@@ -61,6 +61,7 @@ def cpu_baseline(n_relu, get):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     from nngp_src_amd import synth
+    c_oracle.set_threads(min(16, os.cpu_count() or 1))  # the GPU box gives one GPU a 16-core CPU share
     x, y = synth.synthetic_queries(n, d, seed=0)
     xt, _ = synth.synthetic_queries(m, d, seed=1)
     w, b = [1.0] * (n_relu + 1), [0.0] * (n_relu + 1)

@@ -59,6 +59,11 @@ def num_threads() -> int:
     return lib().oracle_num_threads()
 
 
+def set_threads(n: int) -> int:
+    lib().oracle_set_threads(int(n))
+    return num_threads()
+
+
 def kernel_build(x1, x2, get, w_std, b_std):
     x1 = _c(x1)
     x2c = None if x2 is None else _c(x2)

@@ -37,6 +37,14 @@ int oracle_num_threads(void) {
 #endif
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 static void row_sqnorm(const double* x, int64_t n, int d, double* q) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
