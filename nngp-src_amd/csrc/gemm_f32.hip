@@ -5,8 +5,10 @@
 // (lower_only), the panel GEMMs of the triangular solves, the multiplication by inverted diagonal
 // blocks, and the posterior covariance products.
 //
-// Design (CDNA4): 128x128 tile per 256-thread workgroup, 4 waves in a 2x2 grid, each wave owns a
-// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs).  Both operands are
+// Design (CDNA4): 256-thread workgroup = 4 waves in a 2x2 grid; the throughput shape is a 128x128 tile with a
+// 64x64 sub-tile per wave = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs); 64x128 and 64x64 workgroup
+// tiles serve problems with too few tiles to fill 256 CUs (a workgroup's K loop is one serial MFMA chain on one
+// CU).  K tiles are consumed from the high end of K down (see load_tile: accuracy of the Cholesky updates).  Both operands are
 // K-contiguous ("row-major x row-major^T"), so A and B use the same staging path: 16-byte global
 // loads -> registers -> LDS, double-buffered over BK = 32, one barrier per K-step.  LDS rows are
 // 128 bytes; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so that the ds_read_b128

@@ -2,7 +2,8 @@
 // the MFMA solves, the predictive-variance reduction and the covariance epilogue.  Replaces the tail of
 // predict_fn(x_test, get, compute_cov=True) (reference train.py:157-158; estimator.py:66-67):
 //   mean = K_td alpha,  cov = K_tt - K_td (K_dd + reg I)^-1 K_dt,  of which only diag(cov) is consumed
-//   downstream (train.py:180; estimator.py:55), so var_i = K_tt,ii - |L^-1 k_i|^2 is the default.
+//   downstream (train.py:180; estimator.py:55).  The orchestration (float32 solves, float64 correction sweep,
+//   second-order variance formula, NTK covariance) is nngp_model_predict in api.hip.
 #include "common.h"
 
 namespace nngp {

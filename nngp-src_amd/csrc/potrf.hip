@@ -129,11 +129,12 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
                 asm volatile("" : "+v"(inv));
                 const float lij = a[j] * inv;                // L[i][j] for i > j
                 a[j] = (i == j) ? d * inv : lij;
+                const float t = -lij * inv;                  // a[i][k] -= L[i][j] L[k][j] = a[i][k] + t * col[k]
 #pragma unroll
-                for (int k = j + 1; k < 32; ++k) {  // a[i][k] -= L[i][j] L[k][j]
+                for (int k = j + 1; k < 32; ++k) {
                     float ck = col[k];
                     if (VARIANT == 0) asm volatile("" : "+v"(ck));  // stay in VGPRs: scalarising 496 broadcasts spills SGPRs
-                    a[k] = fmaf(-lij, ck * inv, a[k]);
+                    a[k] = fmaf(t, ck, a[k]);
                 }
             }
             if (lane < 32) {
