@@ -1,0 +1,91 @@
+"""Active-learning loop over the GP hot path (reference active/ActiveLearner.py:15-77).
+
+Same control flow as the reference: fit, score a pool by predictive standard deviation relative to max(mean),
+move the `budget` most uncertain (or std-proportionally sampled) pool queries into the training set, refit.
+Each refit is a full kernel build + Cholesky on the GPU (a model handle sized for the final training set is
+reused, so nothing is reallocated between iterations).  Differences from the reference, none of which change
+the deterministic path: only diag(cov) is requested; the biased sampler draws with NumPy's PCG64 seeded with 10
+where the reference uses jax.random.PRNGKey(10) (threefry) -- the draws differ, the distribution does not.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .model import GPModel
+from .util import PredictionStatistics
+
+
+class ActiveLearner(object):
+    def __init__(self, args=None, budget=1000, active_iters=3, kernel_type="nngp", biased_sample=False):
+        self.args = args
+        self.budget = getattr(args, "budget", budget)
+        self.active_iters = getattr(args, "active_iters", active_iters)
+        self.kernel_type = getattr(args, "kernel_type", kernel_type)
+        self.biased_sample = getattr(args, "biased_sample", biased_sample)
+        self.pred_stat = PredictionStatistics()
+        self._model = None
+        self.history = []
+
+    # -- reference: ActiveLearner.train (ActiveLearner.py:23-31) --
+    def train(self, kernel_fn, X_train, Y_train, X_test=None, Y_test=None, n_cap=None):
+        X_train = np.ascontiguousarray(X_train, dtype=np.float64)
+        Y_train = np.ascontiguousarray(Y_train, dtype=np.float64).reshape(X_train.shape[0], -1)
+        n, d = X_train.shape
+        if self._model is None or self._model.n_cap < n or self._model.d != d or self._model.get != self.kernel_type:
+            if self._model is not None:
+                self._model.close()
+            self._model = GPModel(max(n, n_cap or n), d, kernel_fn.w_std, kernel_fn.b_std, get=self.kernel_type,
+                                  diag_reg=1e-3, ny=Y_train.shape[1])
+        self._model.fit(X_train, Y_train)
+
+        def predict_fn(x_test=None, get=None, compute_cov=False):
+            assert get in (None, self.kernel_type)
+            if compute_cov:
+                return self._model.predict(x_test, cov="diag" if compute_cov == "diag" else "full")
+            return self._model.predict(x_test, cov=False)
+
+        return predict_fn
+
+    # -- reference: ActiveLearner.test (ActiveLearner.py:33-40) --
+    def test(self, predict_fn, X_val, Y_val, query_infos_val=None, kernel_type="nngp", compute_cov=True):
+        pred_mean = predict_fn(x_test=X_val, get=kernel_type, compute_cov=False)
+        errors = pred_mean - Y_val
+        mse = float(np.mean(np.power(errors, 2.0)))
+        print("Test MSE Loss:{}".format(mse))
+        self.pred_stat.get_prediction_details(np.ravel(errors), query_infos_val, partition_keys='num_predicates')
+        return mse
+
+    # -- reference: ActiveLearner.active_test (ActiveLearner.py:43-55) --
+    def active_test(self, predict_fn, X_test, kernel_type="nngp"):
+        pred_mean, pred_var = predict_fn(x_test=X_test, get=kernel_type, compute_cov="diag")
+        pred_std = np.sqrt(np.maximum(pred_var, 0.0))
+        pred_std = pred_std / np.max(pred_mean, 0)
+        num_test = X_test.shape[0]
+        pred_std = np.reshape(pred_std, (num_test,))
+        num_select = self.budget if num_test > self.budget else num_test
+        if self.biased_sample:
+            std_prob = pred_std / np.sum(pred_std)
+            return np.random.default_rng(10).choice(num_test, size=num_select, replace=False, p=std_prob)
+        return np.argsort(pred_std)[-num_select:]
+
+    # -- reference: ActiveLearner.merge_data (ActiveLearner.py:57-65) --
+    def merge_data(self, select_indices, X_train, Y_train, X_test, Y_test):
+        X_train_new = np.vstack((X_train, X_test[select_indices]))
+        Y_train_new = np.vstack((Y_train, Y_test[select_indices]))
+        keep = np.setdiff1d(np.arange(X_test.shape[0]), np.asarray(select_indices))
+        return X_train_new, Y_train_new, X_test[keep], Y_test[keep]
+
+    # -- reference: ActiveLearner.active_train (ActiveLearner.py:67-77) --
+    def active_train(self, kernel_fn, X_train, Y_train, X_test, Y_test, X_val, Y_val, query_infos_val=None):
+        print("# Initial Training samples: {}".format(X_train.shape[0]))
+        n_cap = X_train.shape[0] + min(self.budget * self.active_iters, X_test.shape[0])
+        predict_fn = self.train(kernel_fn, X_train, Y_train, n_cap=n_cap)
+        self.history = [self.test(predict_fn, X_val, Y_val, query_infos_val, self.kernel_type)]
+        for i in range(self.active_iters):
+            select_indices = self.active_test(predict_fn, X_test, self.kernel_type)
+            print("Active Iteration {}: Selection {}".format(i, select_indices.shape[0]))
+            X_train, Y_train, X_test, Y_test = self.merge_data(select_indices, X_train, Y_train, X_test, Y_test)
+            print("# Training samples: {}".format(X_train.shape[0]))
+            predict_fn = self.train(kernel_fn, X_train, Y_train, n_cap=n_cap)
+            self.history.append(self.test(predict_fn, X_val, Y_val, query_infos_val, self.kernel_type))
+        return predict_fn
