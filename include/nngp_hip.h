@@ -139,6 +139,19 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  *   L > 2  L-1 sweeps + the second-order formula                                     1e-10 at L = 3 */
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps);
 
+/* ---- N2: native query-line encoder (host code; replaces the per-line Python of estimator/encoder.py:59-97,187-250
+ * and QuerySampler.py:157-221) --------------------------------------------------------------------------------------
+ * schema_text, one directive per line:  "table <name>" | "num <column> <min> <max>" | "cat <column> <num_categories>".
+ * mode 0: multi-join lines "t1,t2@preds_t1@preds_t2@t1,t2,col#...[@card]"; mode 1: single-table lines
+ * "COL,upper,lower#...@card".  nngp_encoder_encode parses '\n'-separated lines into HOST buffers x_out [max_lines, dim]
+ * (float64) and, when with_card != 0, card_out [max_lines]; bit-identical to the reference encoder. */
+typedef struct nngp_encoder nngp_encoder;
+int nngp_encoder_create(nngp_encoder** out, const char* schema_text, int32_t chunk_size, int32_t mode);
+int nngp_encoder_destroy(nngp_encoder* e);
+int32_t nngp_encoder_dim(const nngp_encoder* e);
+int nngp_encoder_encode(const nngp_encoder* e, const char* text, int64_t text_len, int32_t with_card, double* x_out,
+                        double* card_out, int64_t max_lines, int64_t* n_lines_out);
+
 /* ---- building blocks exported for parity tests and the integration notes ----------------------
  * Blocked lower Cholesky of a float32 matrix in place (n multiple of 128, ld >= n).  dinv: workspace of
  * (n/128) * 128*128 floats receiving the inverses of the diagonal blocks.  clamped: device int32.   */

@@ -25,7 +25,8 @@ ABI_SYMBOLS = (
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
-    "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32",
+    "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
+    "nngp_encoder_encode",
 )
 
 
@@ -80,6 +81,10 @@ def load():
     lib.nngp_model_info.argtypes = [vp, ctypes.POINTER(NngpFitInfo)]
     lib.nngp_model_alpha.argtypes = [vp, vp, vp]
     lib.nngp_model_predict.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.nngp_encoder_create.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, i32, i32]
+    lib.nngp_encoder_destroy.argtypes = [vp]
+    lib.nngp_encoder_dim.argtypes = [vp]
+    lib.nngp_encoder_encode.argtypes = [vp, ctypes.c_char_p, i64, i32, vp, vp, i64, ctypes.POINTER(i64)]
     lib.nngp_model_set_refine.argtypes = [vp, i32]
     lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]

@@ -256,3 +256,57 @@ class NNGPEncoder(object):
         X = np.array([self.transform_to_1d_array(*q) for q in all_queries]).reshape(len(all_queries), self.feat_dim)
         Y = np.log2(np.reshape(np.array(all_cards), (len(all_queries), 1)))
         return X, Y
+
+
+class NativeEncoder(object):
+    """The same encodings computed by the C++ encoder inside libnngp_hip.so: one call parses and
+    encodes a whole batch of query lines, so the serving path is not bound by per-line Python."""
+
+    def __init__(self, tables, chunk_size=64, single_table=False):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        lines = []
+        for t in tables:
+            lines.append("table %s" % t.table_name)
+            for c in t.columns:
+                if c.kind == "categorical":
+                    lines.append("cat %s %d" % (c.name, c.num_categories))
+                else:
+                    lines.append("num %s %r %r" % (c.name, float(c.lo), float(c.hi)))
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().nngp_encoder_create(ctypes.byref(self.handle), "\n".join(lines).encode(), int(chunk_size),
+                                                   1 if single_table else 0))
+        self.feat_dim = int(_lib.load().nngp_encoder_dim(self.handle))
+
+    @classmethod
+    def from_encoder(cls, enc):
+        """From a GeneralQueryEncoder (single table) or an NNGPEncoder (multi join)."""
+        if isinstance(enc, NNGPEncoder):
+            return cls(enc.tables, enc.tables[0].chunk_size, single_table=False)
+        return cls([enc], enc.chunk_size, single_table=True)
+
+    def encode_lines(self, lines, with_card=False):
+        """lines: iterable of str -> X [n, d] float64 (and cards [n] when with_card)."""
+        ct = self._ct
+        text = "\n".join(l.strip("\n") for l in lines).encode()
+        cap = text.count(b"\n") + 1
+        x = np.empty((cap, self.feat_dim), dtype=np.float64)
+        cards = np.empty((cap,), dtype=np.float64)
+        n = ct.c_int64(0)
+        self._lib.check(self._lib.load().nngp_encoder_encode(self.handle, text, len(text), int(bool(with_card)),
+                                                             x.ctypes.data_as(ct.c_void_p), cards.ctypes.data_as(ct.c_void_p),
+                                                             cap, ct.byref(n)))
+        x = x[: n.value]
+        return (x, cards[: n.value]) if with_card else x
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.load().nngp_encoder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

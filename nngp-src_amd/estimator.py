@@ -35,6 +35,11 @@ class Estimator(object):
             queries, cards, _ = encoder.load_queries(train_query_path, use_aux, q_error_threshold, coef_var_threshold)
             X_train, Y_train = encoder.transform_to_arrays(queries, cards)
         self.X_train, self.Y_train = np.asarray(X_train, dtype=np.float64), np.asarray(Y_train, dtype=np.float64)
+        try:
+            from .encoder import NativeEncoder
+            self._native = NativeEncoder.from_encoder(self.nngp_encoder)
+        except Exception:  # a user-supplied encoder object without table metadata: keep its Python path
+            self._native = None
         print("Building model kernel ...")
         init_fn, apply_fn, kernel_fn = stax.serial(stax.Dense(512), stax.Relu(), stax.Dense(1))
         kernel_fn = batch(kernel_fn, device_count=0, batch_size=0)
@@ -48,7 +53,10 @@ class Estimator(object):
 
     def predict(self, query_lines):
         start = datetime.datetime.now()
-        X_test = [self.nngp_encoder.parse_line_without_card_then_encode(line) for line in query_lines]
+        if self._native is not None:  # one native call for the whole batch (estimator.py:46-49 loops in Python)
+            X_test = self._native.encode_lines(query_lines, with_card=False)
+        else:
+            X_test = [self.nngp_encoder.parse_line_without_card_then_encode(line) for line in query_lines]
         X_test = np.asarray(X_test, dtype=np.float64).reshape(len(query_lines), self.X_train.shape[1])
         pred_mean, pred_var = self._nngp_prediction(X_test)
         duration = (datetime.datetime.now() - start).total_seconds()

@@ -200,3 +200,52 @@ def test_row_partition():
         assert parts[0][0] == 0 and parts[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         assert all(r1 - r0 <= distributed.row_chunk(n, w) for r0, r1 in parts)
+
+
+def test_native_encoder_is_bit_identical(golden_dir):
+    """The C++ encoder in libnngp_hip.so (host code, no GPU needed) against the golden vectors the REFERENCE encoder
+    produced, and against the Python restatement on fuzzed lines."""
+    gold = json.load(open(os.path.join(golden_dir, "encoder_ref.json")))
+    single = enc.NativeEncoder.from_encoder(enc.GeneralQueryEncoder())
+    assert single.feat_dim == 20
+    x, cards = single.encode_lines([g["line"] for g in gold["forest"]], with_card=True)
+    np.testing.assert_array_equal(x, np.array([g["x"] for g in gold["forest"]]))
+    assert cards[0] == int(gold["forest"][0]["line"].split("@")[1])
+    tables = [enc.TableEncoder(t["name"], [enc.ColumnSpec(c[0], c[1], c[2], c[3], int(c[4])) for c in t["columns"]], 64)
+              for t in gold["join_tables"]]
+    py = enc.NNGPEncoder(tables)
+    nat = enc.NativeEncoder.from_encoder(py)
+    assert nat.feat_dim == py.feat_dim
+    np.testing.assert_array_equal(nat.encode_lines([g["line"] for g in gold["join"]]), np.array([g["x"] for g in gold["join"]]))
+    x, cards = nat.encode_lines([g["line"] + "@%d" % (7 + i) for i, g in enumerate(gold["join"])], with_card=True)
+    np.testing.assert_array_equal(x, np.array([g["x"] for g in gold["join"]]))
+    assert cards.tolist() == [7 + i for i in range(len(gold["join"]))]
+    # fuzz against the Python encoder
+    rng = np.random.default_rng(0)
+    names = [t.table_name for t in tables]
+    lines = []
+    for _ in range(200):
+        k = rng.integers(1, len(tables) + 1)
+        tids = sorted(rng.choice(len(tables), size=k, replace=False).tolist())
+        preds = []
+        for t in tids:
+            ps = []
+            for c in tables[t].columns:
+                if rng.random() < 0.5:
+                    continue
+                if c.kind == "categorical":
+                    cats = rng.choice(c.num_categories, size=rng.integers(1, 4), replace=False)
+                    ps.append("%s,%s" % (c.name, ",".join(str(int(v)) for v in cats)))
+                else:
+                    a, b = sorted(rng.uniform(c.lo - 5, c.hi + 5, 2), reverse=True)
+                    ps.append("%s,%.3f,%.3f" % (c.name, a, b))
+            preds.append("#".join(ps))
+        joins = [j for j in py.all_join_infos if j.t1_id in tids and j.t2_id in tids and rng.random() < 0.7]
+        jstr = "#".join("%s,%s,%s" % (names[j.t1_id], names[j.t2_id], j.col_name) for j in joins)
+        lines.append(",".join(names[t] for t in tids) + "@" + "@".join(preds) + "@" + jstr)
+    want = np.array([py.parse_line_without_card_then_encode(l) for l in lines])
+    np.testing.assert_array_equal(nat.encode_lines(lines), want)
+    with pytest.raises(_lib.NngpError, match="Query Format Error"):
+        nat.encode_lines(["orders,cust@o_id,1,0"])
+    with pytest.raises(_lib.NngpError, match="unknown column"):
+        single.encode_lines(["Z,1,0@5"], with_card=True)
