@@ -54,6 +54,8 @@ class GPModel:
             raise ValueError("x_train must be [N, %d], got %s" % (self.d, tuple(xd.shape)))
         if yd.shape[1] != self.ny:
             raise ValueError("y_train must have %d column(s), got %s" % (self.ny, tuple(yd.shape)))
+        if int(xd.shape[0]) > self.n_cap or xd.shape[0] == 0:
+            raise ValueError("x_train has %d rows; the model was created for 1..%d" % (xd.shape[0], self.n_cap))
         self.n = int(xd.shape[0])
         self._keep = [xd, yd]
         _lib.check(self.lib.nngp_model_set_train(self.handle, _lib.ptr(xd), _lib.ptr(yd), self.n, _lib.stream_ptr()))

@@ -450,3 +450,42 @@ def test_full_forest_run_against_c_oracle(golden_dir):
     for key in pa:
         assert abs(pa[key] - pb[key]) <= 1e-4 * abs(pb[key]), (key, pa[key], pb[key])
     print("forest full run: cg_iters=%d, q-error median %.4f mean %.3f" % (info["refine_iters"], pa["median"], pa["mean"]))
+
+
+def test_edge_cases_small_and_degenerate():
+    """n = 1, duplicated training rows (K singular without the regulariser), zero test rows, many output columns."""
+    a = o.make_arch(1)
+    # a single training query
+    x1 = np.array([[3.0, 4.0, 0.0, 1000.0]]); y1 = np.array([[5.0]])
+    m1 = GPModel(1, 4, a.w_std, a.b_std, diag_reg=1e-3).fit(x1, y1)
+    xt = np.array([[3.0, 4.0, 0.0, 1000.0], [1.0, 0.0, 0.0, 0.0]])
+    mean, var = m1.predict(xt, cov="diag")
+    mref, cref = o.Posterior(x1, y1, a, diag_reg=1e-3).predict(xt, "nngp", True)
+    np.testing.assert_allclose(mean, mref, rtol=1e-9)
+    np.testing.assert_allclose(var, np.diag(cref), rtol=1e-6)
+    # duplicated rows: K is singular, K + reg I is not
+    x, y = synth.synthetic_queries(150, 20, seed=3)
+    xd = np.vstack([x, x[:50]]); yd = np.vstack([y, y[:50] + 0.5])
+    md = GPModel(200, 20, a.w_std, a.b_std, diag_reg=1e-3).fit(xd, yd)
+    info = md.info()
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-9, info
+    xt2, _ = synth.synthetic_queries(30, 20, seed=4)
+    mean, var = md.predict(xt2, cov="diag")
+    mref, cref = o.Posterior(xd, yd, a, diag_reg=1e-3).predict(xt2, "nngp", True)
+    assert G.mean_gate(mean, mref)[0] < 1e-6
+    np.testing.assert_allclose(var, np.diag(cref), rtol=1e-4)
+    # no test rows
+    mean0, var0 = md.predict(np.zeros((0, 20)), cov="diag")
+    assert mean0.shape == (0, 1) and var0.shape == (0,)
+    # three output columns share one factorisation
+    y3 = np.concatenate([yd, yd ** 2 / 10.0, np.cos(yd)], axis=1)
+    m3 = GPModel(200, 20, a.w_std, a.b_std, diag_reg=1e-3, ny=3).fit(xd, y3)
+    mean3, var3 = m3.predict(xt2, cov="diag")
+    mref3, _ = o.Posterior(xd, y3, a, diag_reg=1e-3).predict(xt2, "nngp", True)
+    assert mean3.shape == (30, 3) and G.mean_gate(mean3, mref3)[0] < 1e-6
+    np.testing.assert_allclose(var3, var, rtol=1e-9)
+    # wrong shapes are rejected on the host
+    with pytest.raises(ValueError):
+        md.predict(np.zeros((3, 19)))
+    with pytest.raises(ValueError):
+        GPModel(10, 4, a.w_std, a.b_std).fit(np.zeros((11, 4)), np.zeros((11, 1)))
