@@ -151,17 +151,31 @@ __global__ __launch_bounds__(256) void k_build(BuildArgs a, ArchDev arch, int64_
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, lg = lane >> 4;
 
-    for (int k0 = 0; k0 < a.d; k0 += KC) {
+    // Software pipeline: the global loads of chunk c+1 are issued into registers before chunk c is consumed from LDS,
+    // so their L2 / Infinity Cache latency overlaps the FMAs instead of preceding them.
+    double ra[4], rb[4];
+    auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + 256 * e;
             const int kk = idx & (KC - 1), row = idx >> 4;
             const int kg = k0 + kk;
             const int64_t gi = i0 + row, gj = j0 + row;
-            As[kk * LDS_ + row] = (kg < a.d && gi < i_end) ? a.x1[gi * a.d + kg] : 0.0;
-            Bs[kk * LDS_ + row] = (kg < a.d && gj < j_end) ? a.x2[gj * a.d + kg] : 0.0;
+            ra[e] = (kg < a.d && gi < i_end) ? a.x1[gi * a.d + kg] : 0.0;
+            rb[e] = (kg < a.d && gj < j_end) ? a.x2[gj * a.d + kg] : 0.0;
+        }
+    };
+    load_chunk(0);
+    for (int k0 = 0; k0 < a.d; k0 += KC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;
+            const int kk = idx & (KC - 1), row = idx >> 4;
+            As[kk * LDS_ + row] = ra[e];
+            Bs[kk * LDS_ + row] = rb[e];
         }
         __syncthreads();
+        if (k0 + KC < a.d) load_chunk(k0 + KC);
         if (MFMA) {
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
@@ -311,8 +325,10 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
     };
     int vec_ok = aligned(a.nngp64, a.ld64, 8) && aligned(a.ntk64, a.ld64, 8) && aligned(a.nngp32, a.ld32, 4) &&
                  aligned(a.ntk32, a.ld32, 4) && (a.row_begin % 4 == 0);
-    // Measured (r1g, N=32768, d=128): VALU 10.6 ms, MFMA 13.1 ms -- the k-loop is bound by the global->LDS staging
-    // latency of its 16-deep chunks, not by the FMAs, so the VALU form stays the default until the staging is pipelined.
+    // Measured (scripts/k1_study.py, N=32768): per k-step the VALU Gram costs 0.026 ms (41 TFLOP/s float64), the MFMA
+    // Gram 0.038 ms -- on gfx950 the float64 MFMA rate EQUALS the float64 VALU rate (78.6 TF), so the matrix cores buy
+    // nothing here and add an LDS re-tiling pass; the VALU form is the default.  Where the 11 ms go at d=128, n_relu=3:
+    // 3.0 ms stores + tile overhead, 3.3 ms Gram, 1.7 ms per ReLU layer (sqrt + atan2 in float64).
     if (g_debug[3] == 3)
         hipLaunchKernelGGL(k_build<true>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
     else

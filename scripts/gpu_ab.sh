@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
 for C in cfg3 cfg5; do
-for V in "0=0" "3=2"; do
+for V in "0=0" "3=3"; do
   echo "== $C NNGP_DEBUG=$V"
   NNGP_DEBUG=$V timeout -k 10 300 python bench.py --config $C --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
