@@ -350,7 +350,8 @@ void lookahead_destroy(LookAhead* la) {
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
                         LookAhead* la, hipStream_t user) {
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
-    int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : (n >= 24576 ? 4096 : (n >= 12288 ? 2048 : 1024));
+    // block-column width: 1024 measured best at N = 32768 (119.4 ms; 2048: 121.3, 4096: 123.2, recursion only: 125)
+    int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : 1024;
     nb = (nb / TB) * TB;
     if (la == nullptr || g_debug[2] != 0 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);

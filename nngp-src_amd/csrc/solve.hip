@@ -186,7 +186,10 @@ int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_
     return 0;
 }
 
-int64_t triinv_block(int64_t np) { return np < 1024 ? np : 1024; }
+int64_t triinv_block(int64_t np) {
+    const int64_t bs = g_debug[6] >= 128 ? (int64_t)g_debug[6] : 1024;  // debug key 6: block size experiment
+    return np < bs ? np : bs;
+}
 
 // Inverts the diagonal blocks (size bs, tail np % bs) of the float32 factor: T_J = L_JJ^-T by a batched
 // triangular solve against the identity (MFMA GEMMs), X_J = T_J^T.  Used by the blocked TRSVs below.
