@@ -372,16 +372,19 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         if (rc != 0 || m == 0) break;
         // update stream: triangular solve of the rows below, then the trailing update
         NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_panel[k], 0));
-        rc = trsm_rlt_f32(akk + nbk * ld, ld, m, akk, ld, dk, nbk, la->update);
         const int64_t nb2 = (m < nb) ? m : nb;
         const float* p = akk + nbk * ld;        // panel rows below the diagonal block: [m, nbk]
         float* c = akk + nbk * ld + nbk;        // trailing matrix: [m, m]
-        // next diagonal block first (the panel stream is waiting for it) ...
+        // critical path first: solve only the nb2 panel rows the next diagonal block needs, update that block, and
+        // release the panel stream; the remaining panel rows and the rest of the trailing update follow
+        rc = trsm_rlt_f32(akk + nbk * ld, ld, nb2, akk, ld, dk, nbk, la->update);
         if (rc == 0) rc = launch_gemm_nt_f32(c, ld, p, ld, p, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, la->update);
         NNGP_HIP_CHECK(hipEventRecord(la->ev_col[k], la->update));
-        // ... then the rest of the trailing matrix, overlapped with the factorisation of the next diagonal block
+        // ... then the other panel rows and the rest of the trailing matrix, overlapped with the next diagonal block
         if (rc == 0 && m > nb2) {
-            rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
+            rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
+            if (rc == 0)
+                rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
             if (rc == 0)
                 rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, nbk,
                                         -1.0f, 1.0f, true, la->update);
