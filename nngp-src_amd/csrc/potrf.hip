@@ -297,12 +297,9 @@ int lookahead_create(LookAhead** out) {
     if (g_debug[5] == 2 && ncu >= 64 && panel_cus < ncu) {
         const int words = (ncu + 31) / 32;
         uint32_t mp[16] = {0}, mu[16] = {0};
-        // spread the panel CUs evenly over the device (every (ncu / panel_cus)-th CU) so that each XCD keeps most of its CUs
-        const int stride = ncu / panel_cus;
-        for (int c = 0; c < ncu; ++c) {
-            const bool is_panel = (c % stride == 0) && (c / stride < panel_cus);
-            (is_panel ? mp : mu)[c / 32] |= (1u << (c % 32));
-        }
+        // mask bit i addresses CU (i / 8) of XCD (i % 8) (measured: masks that thin out one XCD make it the straggler of
+        // every GEMM), so the first 8*r bits take r CUs from every XCD
+        for (int c = 0; c < ncu; ++c) (c < panel_cus ? mp : mu)[c / 32] |= (1u << (c % 32));
         if (words <= 16 && hipExtStreamCreateWithCUMask(&la->panel, words, mp) == hipSuccess) {
             if (hipExtStreamCreateWithCUMask(&la->update, words, mu) == hipSuccess) {
                 masked = true;

@@ -1,8 +1,9 @@
 #!/bin/bash
+# A/B timing of NNGP_DEBUG variants on the bench (timing experiments only)
 export TMPDIR=/tmp
-timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
-for C in cfg3 cfg2; do
-for V in "0=0" "1=768" "1=1536"; do
+CFGS=${CFGS:-cfg3}
+for C in $CFGS; do
+for V in "$@"; do
   echo "== $C NNGP_DEBUG=$V"
   NNGP_DEBUG=$V timeout -k 10 300 python bench.py --config $C --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
