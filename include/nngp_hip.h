@@ -161,6 +161,13 @@ int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clampe
 int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
                      int64_t m, int64_t n, int64_t k, float alpha, float beta, int32_t lower_only,
                      void* stream);
+/* Same product with both operands split into two float16 planes (a*scale = hi + lo) and three float16 MFMA products
+ * per term, float32 accumulation: float32-grade results at 3/16 of the float32 matrix-pipe cost.  scale: power of two
+ * with max|a*scale|, max|b*scale| <= 2^14.  M, N multiples of 128, K of 32.  Allocates and frees its own split
+ * workspace (the Cholesky keeps one per model); a test / integration primitive like the two above.      */
+int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
+                    int64_t m, int64_t n, int64_t k, float alpha, float beta, float scale, int32_t lower_only,
+                    void* stream);
 /* C[M,N] = beta*Cin + alpha * A[M,K] B[N,K]^T on float64 MFMA (M, N multiples of 128, K of 16; Cin may be C). */
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                      const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
-    "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
+    "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode",
 )
 
@@ -89,6 +89,8 @@ def load():
     lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.nngp_gemm_nt_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float, i32, vp]
+    lib.nngp_gemm_nt_h3.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, i32, vp]
     lib.nngp_trsm_rlt_f32.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp]
     for name in ABI_SYMBOLS:
         if name != "nngp_last_error":

@@ -74,6 +74,8 @@ struct nngp_model {
     PcgWork pcg{};
     TriInv tri{};
     LookAhead* la = nullptr;
+    SplitWork split{};
+    double diag_max = 0.0;
 
     // predict-side buffers (grown on demand when m > m_cap)
     double* xt_q = nullptr;      // [m_cap]
@@ -112,6 +114,7 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
+        dev_free(split.planes);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
@@ -119,6 +122,7 @@ struct nngp_model {
 
 namespace {
 
+// out[0] = max(a), out[1] = sum(a)
 __global__ __launch_bounds__(1024) void k_sum(const double* __restrict__ a, int64_t n, double* out) {
     __shared__ double red[16];
     double s = 0.0;
@@ -129,7 +133,18 @@ __global__ __launch_bounds__(1024) void k_sum(const double* __restrict__ a, int6
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += red[w];
-        *out = t;
+        out[1] = t;
+    }
+    __syncthreads();
+    double mx = -1.0e300;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) mx = fmax(mx, a[i]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int w = 1; w < 16; ++w) t = fmax(t, red[w]);
+        out[0] = t;
     }
 }
 
@@ -345,6 +360,11 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         rc = -1;
     }
     if (rc == 0) rc = lookahead_create(&m->la);
+    if (rc == 0 && np >= 4 * kLookAheadNb) {  // the look-ahead factorisation keeps a float16-split copy of one block column
+        m->split.rows_cap = np + 256;
+        m->split.k_cap = kLookAheadNb;
+        rc = dev_alloc(&m->split.planes, m->split.rows_cap * m->split.k_cap * 4);
+    }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {
         delete m;
@@ -374,11 +394,18 @@ int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_
     NNGP_TRY(launch_row_sqnorm(m->x, n, m->d, m->q, s));
     NNGP_TRY(launch_diag_from_q(m->q, n, m->arch, m->get == NNGP_GET_NNGP ? m->kdiag : nullptr,
                                 m->get == NNGP_GET_NTK ? m->kdiag : nullptr, s));
-    hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, m->kdiag, n, m->pcg.scal + 7);
-    NNGP_HIP_CHECK(hipMemcpyAsync(m->pcg.host_scal + 7, m->pcg.scal + 7, sizeof(double), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, m->kdiag, n, m->pcg.scal + 6);  // [6] = max, [7] = sum
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->pcg.host_scal + 6, m->pcg.scal + 6, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     NNGP_HIP_CHECK(hipStreamSynchronize(s));
     m->trace_mean = m->pcg.host_scal[7] / (double)n;
+    m->diag_max = m->pcg.host_scal[6];
     m->reg = m->absolute ? m->diag_reg : m->diag_reg * m->trace_mean;
+    {   // |L_ij| <= sqrt(max_i A_ii): scale the float16 split so that the largest entry sits at <= 2^14
+        const double lmax = sqrt(fmax(m->diag_max, m->trace_mean) + m->reg);
+        int e = 0;
+        (void)frexp(lmax, &e);  // lmax = f * 2^e, f in [0.5, 1)
+        m->split.scale = (lmax > 0.0 && std::isfinite(lmax)) ? (float)ldexp(1.0, 14 - e) : 1.0f;
+    }
     m->have_train = true;
     return 0;
 }
@@ -446,7 +473,7 @@ int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** d
 int nngp_model_factor(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_TRY(nngp_model_factor_begin(m, stream));
-    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, s));
+    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, &m->split, s));
     return nngp_model_factor_end(m, stream);
 }
 
@@ -633,6 +660,25 @@ int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const f
                      int64_t n, int64_t k, float alpha, float beta, int32_t lower_only, void* stream) {
     NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr, "gemm_nt_f32: NULL argument");
     return launch_gemm_nt_f32(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only != 0, (hipStream_t)stream);
+}
+
+int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n,
+                    int64_t k, float alpha, float beta, float scale, int32_t lower_only, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr && scale > 0.0f, "gemm_nt_h3: bad argument");
+    NNGP_REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "gemm_nt_h3: k must be a multiple of 32");
+    const int64_t mp = round_up(m, 256), np = round_up(n, 256), ldp = 4 * k;
+    char* pa = nullptr;
+    NNGP_HIP_CHECK(hipMalloc((void**)&pa, (size_t)((mp + np) * ldp)));
+    NNGP_HIP_CHECK(hipMemsetAsync(pa, 0, (size_t)((mp + np) * ldp), s));
+    char* pb = pa + mp * ldp;
+    int rc = launch_split_rows(a, lda, m, k, scale, pa, ldp, s);
+    if (rc == 0) rc = launch_split_rows(b, ldb, n, k, scale, pb, ldp, s);
+    if (rc == 0)
+        rc = launch_gemm_nt_h3(c, ldc, pa, pb, ldp, m, n, k, alpha / (scale * scale), beta, lower_only != 0, 0, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(pa);
+    return rc;
 }
 
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,

@@ -79,11 +79,23 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
                                int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int batch,
                                int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s);
 
+// ---- gemm_h3.hip: float32-grade products on the float16 matrix pipe (two float16 planes per operand) ----
+int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,
+                      hipStream_t s);
+int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
+                      float alpha, float beta, bool lower_only, int64_t diag_shift, hipStream_t s);
+
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
 int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s);
 int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
                  hipStream_t s);
+
+struct SplitWork {   // float16-split copy of the current block column (gemm_h3.hip); one per model
+    char* planes = nullptr;   // [rows_cap][k_cap] x 4 bytes
+    int64_t rows_cap = 0, k_cap = 0;
+    float scale = 1.0f;       // power of two, max |L_ij| * scale <= 2^14
+};
 
 struct LookAhead {  // streams and events of the look-ahead Cholesky (one per model)
     static constexpr int kMaxSteps = 64;
@@ -95,7 +107,8 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
 int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
-                        LookAhead* la, hipStream_t user);
+                        LookAhead* la, const SplitWork* sw, hipStream_t user);
+constexpr int64_t kLookAheadNb = 1024;  // block-column width of the look-ahead Cholesky
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
                     int64_t w, hipStream_t s);
 int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s);

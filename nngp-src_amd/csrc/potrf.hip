@@ -345,12 +345,15 @@ void lookahead_destroy(LookAhead* la) {
 }
 
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
-                        LookAhead* la, hipStream_t user) {
+                        LookAhead* la, const SplitWork* sw, hipStream_t user) {
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
     // block-column width: 1024 measured best at N = 32768 (119.4 ms; 2048: 121.3, 4096: 123.2, recursion only: 125)
-    int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : 1024;
+    int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : kLookAheadNb;
     nb = (nb / TB) * TB;
-    if (la == nullptr || g_debug[2] != 0 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
+    // large trailing updates on the float16 matrix pipe (gemm_h3.hip) unless the workspace is missing / too small or
+    // debug key 2 == 2 asks for the float32-MFMA updates (A/B timing)
+    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->k_cap >= nb && sw->rows_cap >= n + 256 && g_debug[2] != 2;
+    if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
@@ -380,11 +383,20 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         // ... then the other panel rows and the rest of the trailing matrix, overlapped with the next diagonal block
         if (rc == 0 && m > nb2) {
             rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
-            if (rc == 0)
-                rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
-            if (rc == 0)
-                rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, nbk,
-                                        -1.0f, 1.0f, true, la->update);
+            if (h3) {
+                // one launch: rows [nb2, m) x columns [0, m) of the trailing matrix, on or below its diagonal
+                const int64_t ldp = 4 * sw->k_cap;
+                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes, ldp, la->update);
+                if (rc == 0)
+                    rc = launch_gemm_nt_h3(c + nb2 * ld, ld, sw->planes + nb2 * ldp, sw->planes, ldp, m - nb2, m, nbk,
+                                           -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, la->update);
+            } else {
+                if (rc == 0)
+                    rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
+                if (rc == 0)
+                    rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, nbk,
+                                            -1.0f, 1.0f, true, la->update);
+            }
         }
     }
     NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, la->panel));

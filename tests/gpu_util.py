@@ -37,6 +37,15 @@ def gemm_nt(c, a, b, alpha, beta, lower_only=False):
     torch.cuda.synchronize()
 
 
+def gemm_nt_h3(c, a, b, alpha, beta, scale, lower_only=False):
+    lib = _lib.load()
+    m, k = a.shape
+    n = b.shape[0]
+    _lib.check(lib.nngp_gemm_nt_h3(_lib.ptr(c), c.stride(0), _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0),
+                                   m, n, k, alpha, beta, scale, int(lower_only), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+
+
 def gemm_nt_f64(c, cin, a, b, alpha, beta):
     lib = _lib.load()
     m, k = a.shape
