@@ -114,7 +114,7 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
-        dev_free(split.planes);
+        dev_free(split.planes); dev_free(split.counters);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
@@ -364,6 +364,7 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         m->split.rows_cap = np + 256;
         m->split.k_cap = kLookAheadNb;
         rc = dev_alloc(&m->split.planes, m->split.rows_cap * m->split.k_cap * 4);
+        if (rc == 0) rc = dev_alloc(&m->split.counters, 8);
     }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {
@@ -433,6 +434,7 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
     NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
+    m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
     return 0;
 }
@@ -669,13 +671,15 @@ int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const fl
     NNGP_REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "gemm_nt_h3: k must be a multiple of 32");
     const int64_t mp = round_up(m, 256), np = round_up(n, 256), ldp = 4 * k;
     char* pa = nullptr;
-    NNGP_HIP_CHECK(hipMalloc((void**)&pa, (size_t)((mp + np) * ldp)));
-    NNGP_HIP_CHECK(hipMemsetAsync(pa, 0, (size_t)((mp + np) * ldp), s));
+    NNGP_HIP_CHECK(hipMalloc((void**)&pa, (size_t)((mp + np) * ldp + 64)));
+    NNGP_HIP_CHECK(hipMemsetAsync(pa, 0, (size_t)((mp + np) * ldp + 64), s));
     char* pb = pa + mp * ldp;
+    int* counters = reinterpret_cast<int*>(pb + np * ldp);
     int rc = launch_split_rows(a, lda, m, k, scale, pa, ldp, s);
     if (rc == 0) rc = launch_split_rows(b, ldb, n, k, scale, pb, ldp, s);
     if (rc == 0)
-        rc = launch_gemm_nt_h3(c, ldc, pa, pb, ldp, m, n, k, alpha / (scale * scale), beta, lower_only != 0, 0, s);
+        rc = launch_gemm_nt_h3(c, ldc, pa, pb, ldp, m, n, k, alpha / (scale * scale), beta, lower_only != 0, 0, counters,
+                               g_debug[4] > 0 ? g_debug[4] : 0, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(pa);
     return rc;

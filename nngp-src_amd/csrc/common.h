@@ -83,7 +83,8 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
 int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,
                       hipStream_t s);
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
-                      float alpha, float beta, bool lower_only, int64_t diag_shift, hipStream_t s);
+                      float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
+                      hipStream_t s);
 
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
@@ -95,6 +96,7 @@ struct SplitWork {   // float16-split copy of the current block column (gemm_h3.
     char* planes = nullptr;   // [rows_cap][k_cap] x 4 bytes
     int64_t rows_cap = 0, k_cap = 0;
     float scale = 1.0f;       // power of two, max |L_ij| * scale <= 2^14
+    int* counters = nullptr;  // 8 work counters of the persistent GEMM grid (one per XCD)
 };
 
 struct LookAhead {  // streams and events of the look-ahead Cholesky (one per model)

@@ -12,9 +12,11 @@
 // max|a*s| <= 2^14 (no float16 overflow; entries down to 2^-16 of the largest keep all 22 bits).
 //
 // Kernel: 512-thread workgroup = 8 waves (2 x 4), tile 256x256, wave sub-tile 128x64 = 4x2 accumulators of 32x32
-// (128 VGPRs), BK = 32 per stage (two k16 MFMA sub-steps), LDS 2 stages x 64 KB, 128-byte rows with the 16-byte chunk
-// index XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128, same image geometry as gemm_f32.hip).  K blocks are
-// consumed from the high end down (accumulation order of the Cholesky updates, see gemm_f32.hip).
+// (128 VGPRs), BK = 32 per stage (two k16 MFMA sub-steps), LDS 2 stages x 64 KB filled by global_load_lds_dwordx4,
+// 128-byte rows with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 (conflict-free for the ds_read_b128 lane
+// groups of gfx950).  K blocks are consumed from the high end down (accumulation order of the Cholesky updates, see
+// gemm_f32.hip).  The grid is persistent: one workgroup per compute unit (128 KB of LDS each) pulls tiles from per-XCD
+// work counters, which lets the caller keep a few compute units free for a concurrent latency-critical stream.
 #include "common.h"
 
 namespace nngp {
@@ -54,106 +56,193 @@ __global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ p,
     *reinterpret_cast<h8*>(dst + 64) = lo;
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// number of valid block columns of block row gr (blocks of br x bc tiles); lower: tiles with bj <= bi + sh_t
+__host__ __device__ __forceinline__ int h3_block_cols(int gr, int br, int bc, int tiles_m, int tiles_n, bool lower, int sh_t) {
+    int last = tiles_n - 1;
+    if (lower) {
+        int rmax = gr * br + br - 1;
+        if (rmax > tiles_m - 1) rmax = tiles_m - 1;
+        if (rmax + sh_t < last) last = rmax + sh_t;
+    }
+    return last / bc + 1;
+}
+
+// Tile order: the workgroups with blockIdx % 8 == x run on XCD x and share the work counter x; slot s of XCD x is tile
+// (s % (br*bc)) of tile block (s / (br*bc)) * 8 + x, blocks of br x bc tiles enumerated row by row over the blocks that
+// contain work -- so the workgroups resident on an XCD share br A panels and bc B panels through its L2.
+//
 // LOWER: only tiles that touch the region col <= row + diag_shift are computed, and inside them only the 32x32
 // sub-tiles whose 128-block column index <= 128-block row index (the same element set the float32 kernel writes).
+//
+// Schedule inside a tile: waves 0-3 (upper 128 rows, group 0) and waves 4-7 (group 1) run the identical phase sequence
+// one barrier apart, so on every SIMD one wave is inside its MFMA cluster while the other issues its LDS fragment reads
+// and its direct-to-LDS loads.  Phase = { ds_read fragments of one k16 sub-step; lgkmcnt(0); barrier; 24 MFMA; barrier };
+// two phases per BK = 32 stage, raw s_barrier only (a __syncthreads would drain the loads in flight).
+// Hazards (b = buffer of stage t; G1's barriers pair with G0's next one):
+//   WAR  stage t+1 is loaded into buffer 1-b after the issuing group's last barrier of stage t-1; the other group's
+//        last reads of that buffer were retired by the lgkmcnt(0) in front of the barrier paired with it.
+//   RAW  a group reads in stage t+1 only pieces whose loading waves executed vmcnt(0) before a barrier the reader has
+//        passed: G0 loads all B rows and A rows 0-127 (everything G0 reads; G1 reads B one barrier later still), G1 loads
+//        A rows 128-255 (read by G1 only).
+// ablate (timing diagnostics only): 1 no operand loads after the first stage, 2 no MFMA, 8 no C traffic.
 template <bool LOWER>
 __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const char* A, const char* B, int64_t ldp,
                                                     int m, int n, int tiles_m, int nk, float alpha, float beta,
-                                                    int diag_shift) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * HSTAGE];
+                                                    int diag_shift, int order_br, int order_bc, int* counters,
+                                                    int slots_per_xcd, int ablate) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * HSTAGE];
+    __shared__ int s_slot;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int bi = blockIdx.x % tiles_m, bj = blockIdx.x / tiles_m;  // row tiles fastest: neighbours share the B rows
-    if (LOWER && bj * HT > bi * HT + HT - 1 + diag_shift) return;
-
-    const char* Ab = A + (int64_t)bi * HT * ldp;
-    const char* Bb = B + (int64_t)bj * HT * ldp;
-    const int lr = tid >> 3, ch = tid & 7;
-    u32x4 ga[4], gb[4];
-    auto load_tile = [&](int t) {
-        const int64_t off = (int64_t)(nk - 1 - t) * 128 + ch * 16;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ga[e] = *reinterpret_cast<const u32x4*>(Ab + (int64_t)(lr + 64 * e) * ldp + off);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gb[e] = *reinterpret_cast<const u32x4*>(Bb + (int64_t)(lr + 64 * e) * ldp + off);
-    };
-    auto store_tile = [&](int buf) {
-        char* sa_ = smem + buf * HSTAGE;
-        char* sb_ = sa_ + HT * HROW;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x4*>(sa_ + lds_off(lr + 64 * e, ch)) = ga[e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x4*>(sb_ + lds_off(lr + 64 * e, ch)) = gb[e];
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
+    const int tiles_n = (n + HT - 1) / HT;
+    const int xcd = blockIdx.x & 7;
+    const int group = __builtin_amdgcn_readfirstlane(wr);
+    const int w4 = __builtin_amdgcn_readfirstlane(wc);
+    const int l3 = lane >> 3;
     const int frow = lane & 31, fh = lane >> 5;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) load_tile(t + 1);
-        const char* sa_ = smem + (t & 1) * HSTAGE;
-        const char* sb_ = sa_ + HT * HROW;
-#pragma unroll
-        for (int kk = 1; kk >= 0; --kk) {
-            h8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wr * 128 + i * 32 + frow;
-                ah[i] = *reinterpret_cast<const h8*>(sa_ + lds_off(row, kk * 2 + fh));
-                al[i] = *reinterpret_cast<const h8*>(sa_ + lds_off(row, 4 + kk * 2 + fh));
+    // direct-to-LDS pieces of 8 rows: wave (group g, index w4) moves A pieces g*16 + e*4 + w4 (e < 4) and, in group 0,
+    // B pieces e*4 + w4 (e < 8).  piece parity = w4 & 1, so the source swizzle is one per-lane constant.
+    const int64_t lane_off = (int64_t)l3 * ldp + (((lane & 7) ^ ((4 * (w4 & 1) + (l3 >> 1)) & 7)) << 4);
+
+    for (;;) {
+        if (tid == 0) s_slot = atomicAdd(&counters[xcd], 1);
+        __syncthreads();
+        const int slot = s_slot;
+        __syncthreads();  // s_slot may be rewritten only after every wave has read it
+        if (slot >= slots_per_xcd) break;
+        int bi, bj;
+        {
+            const int per = order_br * order_bc;
+            int G = (slot / per) * 8 + xcd;
+            const int i = slot % per;
+            const int brows = (tiles_m + order_br - 1) / order_br;
+            const int sh_t = (diag_shift + HT - 1) / HT;
+            int gr = 0;
+            for (; gr < brows; ++gr) {
+                const int cnt = h3_block_cols(gr, order_br, order_bc, tiles_m, tiles_n, LOWER, sh_t);
+                if (G < cnt) break;
+                G -= cnt;
             }
+            if (gr >= brows) continue;
+            bi = gr * order_br + (i % order_br);
+            bj = G * order_bc + (i / order_br);
+            if (bi >= tiles_m || bj >= tiles_n) continue;
+        }
+        if (LOWER && bj * HT > bi * HT + HT - 1 + diag_shift) continue;
+
+        const char* Ab = A + (int64_t)bi * HT * ldp;
+        const char* Bb = B + (int64_t)bj * HT * ldp;
+        auto glds_stage = [&](int t, int buf) {
+            const int64_t koff = (int64_t)(nk - 1 - t) * 128 + lane_off;
+            char* dst = smem + buf * HSTAGE;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wc * 64 + j * 32 + frow;
-                bh[j] = *reinterpret_cast<const h8*>(sb_ + lds_off(row, kk * 2 + fh));
-                bl[j] = *reinterpret_cast<const h8*>(sb_ + lds_off(row, 4 + kk * 2 + fh));
+            for (int e = 0; e < 4; ++e) {
+                const int piece = group * 16 + e * 4 + w4;
+                __builtin_amdgcn_global_load_lds((glb_void*)(Ab + (int64_t)piece * 8 * ldp + koff),
+                                                 (lds_void*)(dst + piece * 1024), 16, 0, 0);
             }
+            if (group == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int e = 0; e < 8; ++e) {
+                    const int piece = e * 4 + w4;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Bb + (int64_t)piece * 8 * ldp + koff),
+                                                     (lds_void*)(dst + HT * HROW + piece * 1024), 16, 0, 0);
+                }
+            }
+        };
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        glds_stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (group == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind group 0
+        for (int t = 0; t < nk; ++t) {
+            const char* sa_ = smem + (t & 1) * HSTAGE;
+            const char* sb_ = sa_ + HT * HROW;
+#pragma unroll
+            for (int kk = 1; kk >= 0; --kk) {
+                h8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    const int row = wc * 64 + j * 32 + frow;
+                    bh[j] = *reinterpret_cast<const h8*>(sb_ + lds_off(row, kk * 2 + fh));
+                    bl[j] = *reinterpret_cast<const h8*>(sb_ + lds_off(row, 4 + kk * 2 + fh));
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wr * 128 + i * 32 + frow;
+                    ah[i] = *reinterpret_cast<const h8*>(sa_ + lds_off(row, kk * 2 + fh));
+                    al[i] = *reinterpret_cast<const h8*>(sa_ + lds_off(row, 4 + kk * 2 + fh));
+                }
+                if (kk == 1 && t + 1 < nk && !(ablate & 1)) glds_stage(t + 1, (t + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if (!(ablate & 2)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                } else {  // keep the fragment reads alive without the matrix work
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage t+1 have landed
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (t + 1 < nk) store_tile((t + 1) & 1);
-        __syncthreads();
-    }
+        if (group == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
 
-    // epilogue: acc[i][j][r] is element (row, col) with row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
-    const int row_base = bi * HT + wr * 128;
-    const int col_base = bj * HT + wc * 64;
+        // epilogue: acc[i][j][r] is element (row, col) with row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+        const int row_base = bi * HT + wr * 128;
+        const int col_base = bj * HT + wc * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r0 = row_base + i * 32, c0 = col_base + j * 32;
-            if (r0 >= m || c0 >= n) continue;  // m, n are multiples of 128: a 32x32 sub-tile is inside or outside
-            if (LOWER && (c0 >> 7) > ((r0 + diag_shift) >> 7)) continue;
-            float* p0 = C + (int64_t)(r0 + 4 * fh) * ldc + c0 + frow;
-            float cold[16];
-            if (beta != 0.0f) {
+            for (int j = 0; j < 2; ++j) {
+                const int r0 = row_base + i * 32, c0 = col_base + j * 32;
+                if (r0 >= m || c0 >= n) continue;  // m, n are multiples of 128: a 32x32 sub-tile is inside or outside
+                if (LOWER && (c0 >> 7) > ((r0 + diag_shift) >> 7)) continue;
+                if (ablate & 8) {
+                    asm volatile("" ::"v"(acc[i][j]));
+                    continue;
+                }
+                float* p0 = C + (int64_t)(r0 + 4 * fh) * ldc + c0 + frow;
+                float cold[16];
+                if (beta != 0.0f) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cold[r] = p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc];
+                    for (int r = 0; r < 16; ++r) cold[r] = p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = alpha * acc[i][j][r];
+                    if (beta != 0.0f) v = fmaf(beta, cold[r], v);
+                    p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+                }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = alpha * acc[i][j][r];
-                if (beta != 0.0f) v = fmaf(beta, cold[r], v);
-                p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
-            }
-        }
+    }
 }
 
 }  // namespace
@@ -172,23 +261,48 @@ int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float
 }
 
 // a, b: split rows (row stride ldp bytes); rows of a / b up to the next multiple of 256 must be readable (their
-// products are never stored).  m, n multiples of 128; k a multiple of 32.
+// products are never stored).  m, n multiples of 128; k a multiple of 32.  counters: 8 device ints owned by the caller
+// (zeroed here, on the stream).  reserve_cus: compute units left free for other streams (the grid is one workgroup
+// per remaining unit).
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
-                      float alpha, float beta, bool lower_only, int64_t diag_shift, hipStream_t s) {
+                      float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
+                      hipStream_t s) {
     if (m <= 0 || n <= 0) return 0;
     NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k > 0 && k % 32 == 0 && diag_shift % 128 == 0 && diag_shift >= 0,
                  "gemm_nt_h3: m, n must be multiples of 128 and k of 32 (m=%lld n=%lld k=%lld)", (long long)m,
                  (long long)n, (long long)k);
-    NNGP_REQUIRE(ldp >= 4 * k && ldp % 16 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ldc >= n,
+    NNGP_REQUIRE(ldp >= 4 * k && ldp % 16 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ldc >= n &&
+                     counters != nullptr,
                  "gemm_nt_h3: operands must be 16-byte aligned");
     const int64_t tm = (m + HT - 1) / HT, tn = (n + HT - 1) / HT;
-    NNGP_REQUIRE(tm * tn < 2147483647LL && m < 2147483647LL && n < 2147483647LL, "gemm_nt_h3: grid too large");
+    NNGP_REQUIRE(m < 2147483647LL && n < 2147483647LL, "gemm_nt_h3: matrix too large");
+    // tile-block shape (debug key 5 = 10 + variant for A/B timing); 4 x 4 measured best at N = 8k .. 32k
+    static const int kOrders[][2] = {{4, 4}, {8, 4}, {4, 8}, {2, 8}, {8, 2}, {8, 8}, {2, 16}, {2, 4}};
+    const int variant = (g_debug[5] >= 10 && g_debug[5] < 18) ? g_debug[5] - 10 : 0;
+    const int br = kOrders[variant][0], bc = kOrders[variant][1];
+    int64_t nblk = 0;
+    for (int64_t gr = 0; gr < (tm + br - 1) / br; ++gr)
+        nblk += h3_block_cols((int)gr, br, bc, (int)tm, (int)tn, lower_only, (int)((diag_shift + HT - 1) / HT));
+    const int64_t slots_per_xcd = ((nblk + 7) / 8) * br * bc;
+    NNGP_REQUIRE(slots_per_xcd < 2147483647LL / 8, "gemm_nt_h3: too many tiles");
+    static int ncu = 0;
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    int64_t grid = ncu - reserve_cus;
+    if (grid > slots_per_xcd * 8) grid = slots_per_xcd * 8;
+    grid = (grid / 8) * 8;  // the same number of workgroups on every XCD
+    if (grid < 8) grid = 8;
+    NNGP_HIP_CHECK(hipMemsetAsync(counters, 0, 8 * sizeof(int), s));
     if (lower_only)
-        hipLaunchKernelGGL(k_gemm_nt_h3<true>, dim3((unsigned)(tm * tn)), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m,
-                           (int)n, (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift);
+        hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
+                           (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters, (int)slots_per_xcd,
+                           g_debug[0] & 11);
     else
-        hipLaunchKernelGGL(k_gemm_nt_h3<false>, dim3((unsigned)(tm * tn)), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m,
-                           (int)n, (int)tm, (int)(k / 32), alpha, beta, 0);
+        hipLaunchKernelGGL((k_gemm_nt_h3<false>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
+                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, g_debug[0] & 11);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

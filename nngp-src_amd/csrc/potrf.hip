@@ -352,7 +352,9 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     nb = (nb / TB) * TB;
     // large trailing updates on the float16 matrix pipe (gemm_h3.hip) unless the workspace is missing / too small or
     // debug key 2 == 2 asks for the float32-MFMA updates (A/B timing)
-    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->k_cap >= nb && sw->rows_cap >= n + 256 && g_debug[2] != 2;
+    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap >= nb && sw->rows_cap >= n + 256 && g_debug[2] != 2;
+    // (measured and dropped: inverting each diagonal block on the panel stream as it is factored -- neutral, 59.1 vs
+    // 58.9 ms -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
@@ -384,12 +386,17 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         if (rc == 0 && m > nb2) {
             rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
             if (h3) {
+                // the persistent GEMM grid leaves `reserve` compute units to the panel stream, whose small kernels
+                // otherwise queue behind 128-KB-LDS workgroups (measured at N = 32768: 0/8/16 -> 62.7 ms, 32 -> 58.7,
+                // 24 -> 65.0, 48 -> 58.8, 64 -> 60.4; debug key 4 overrides)
+                const int reserve = g_debug[4] > 0 ? g_debug[4] : 32;
                 // one launch: rows [nb2, m) x columns [0, m) of the trailing matrix, on or below its diagonal
                 const int64_t ldp = 4 * sw->k_cap;
                 if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes, ldp, la->update);
                 if (rc == 0)
                     rc = launch_gemm_nt_h3(c + nb2 * ld, ld, sw->planes + nb2 * ldp, sw->planes, ldp, m - nb2, m, nbk,
-                                           -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, la->update);
+                                           -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, sw->counters, reserve,
+                                           la->update);
             } else {
                 if (rc == 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);

@@ -16,8 +16,15 @@ byq = collections.defaultdict(list)
 for r in reg: byq[r["Queue_Id"]].append(r)
 for q, rs in byq.items():
     busy = sum(r["e"] - r["s"] for r in rs)
-    names = collections.Counter(("leaf" if "leaf" in r["Kernel_Name"] else r["Kernel_Name"].split("k_gemm_nt_f32")[-1][:14]) for r in rs)
-    print("queue", q, "n", len(rs), "busy ms", busy / 1e6, "span ms", (rs[-1]["e"] - rs[0]["s"]) / 1e6, dict(names))
+    def short(nm):
+        for key in ("leaf", "k_gemm_nt_h3", "k_split_rows"):
+            if key in nm: return key
+        return nm.split("k_gemm_nt_f32")[-1][:14]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rs:
+        a = agg[short(r["Kernel_Name"])]; a[0] += 1; a[1] += (r["e"] - r["s"]) / 1e6
+    print("queue", q, "n", len(rs), "busy ms", round(busy / 1e6, 2), "span ms", round((rs[-1]["e"] - rs[0]["s"]) / 1e6, 2))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]): print("    ", k, v[0], round(v[1], 3))
 leaves = [r for r in reg if "leaf" in r["Kernel_Name"]]
 d = sorted((r["e"] - r["s"]) / 1e3 for r in leaves)
 print("leaf us: min %.1f med %.1f p90 %.1f max %.1f" % (d[0], d[len(d) // 2], d[int(len(d) * .9)], d[-1]))
