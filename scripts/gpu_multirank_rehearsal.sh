@@ -3,6 +3,7 @@
 # Checks the sharded build + all-gather + block-cyclic Cholesky path end to end on the real kernels, and that
 # alpha agrees with the single-rank run (alpha_l2 printed in fit_info).
 export NNGP_DIST_BACKEND=gloo TMPDIR=/tmp
+export NNGP_DIST_MODE=${NNGP_DIST_MODE:-shard}   # the sharded layout is what needs rehearsing; 'replicate' has no collective
 CFG=${1:-cfg2}
 timeout -k 10 300 python bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/rehearsal_g1.json 2> gpurun_out/rehearsal_g1.err
 for G in 2 4; do

@@ -26,7 +26,7 @@ def load(d, cfg):
 def short(name):
     for key in ("k_gemm_nt_f32<2, 2, false>", "k_gemm_nt_f32<2, 2, true>", "k_gemm_nt_f32<1, 2, false>", "k_gemm_nt_f32<1, 1, false>",
                 "k_gemm_nt_f32<1, 1, true>", "k_gemm_nt_f64", "k_potrf_leaf", "k_build", "k_gemv_f64", "k_gemv_n_f32",
-                "k_gemv_t_partial_f32", "k_factor_input", "k_transpose_f32"):
+                "k_gemv_t_partial_f32", "k_factor_input", "k_transpose_f32", "k_gemm_nt_h3", "k_split_rows"):
         if key in name:
             return key
     return None
@@ -48,8 +48,9 @@ def main():
             continue
         e = out["kernels"].setdefault(k, {"calls": calls, "fetch_bytes": 0.0, "write_bytes": 0.0})
         e["write_bytes"] += kib * 1024
-    chol = [k for k in out["kernels"] if k.startswith("k_gemm_nt_f32") or k == "k_potrf_leaf"]
-    out["f32_gemm_and_leaf_bytes"] = sum(out["kernels"][k]["fetch_bytes"] + out["kernels"][k]["write_bytes"] for k in chol)
+    chol = [k for k in out["kernels"] if k.startswith("k_gemm_nt_f32") or k in ("k_potrf_leaf", "k_gemm_nt_h3", "k_split_rows")]
+    out["cholesky_bytes_note"] = "float32/split-float16 GEMM + leaf + split kernels of the step (the posterior's float32 GEMMs included)"
+    out["cholesky_bytes"] = sum(out["kernels"][k]["fetch_bytes"] + out["kernels"][k]["write_bytes"] for k in chol)
     print(json.dumps(out, indent=1))
 
 
