@@ -157,6 +157,75 @@ def test_gemm_random(m, n, k):
     assert torch.all(c[tile_upper] == 0)  # tiles above the diagonal are never touched
 
 
+def test_gemm_split_f16_exact_on_integers():
+    """Split-float16 GEMM: integers up to 2^11 are exact in the hi plane, so the product is exact in float32
+    (asymmetric operands and A = I catch lane-map and tile-index mistakes; K blocks are walked high to low)."""
+    torch.manual_seed(11)
+    m, n, k = 384, 640, 96  # not multiples of the 256 tile: edge tiles, masked stores
+    b = torch.randint(-8, 9, (n, k), device=G.dev()).float()
+    a = torch.zeros((m, k), device=G.dev())
+    a[torch.arange(96), torch.arange(96)] = 1.0
+    c = torch.full((m, n), float("nan"), device=G.dev())
+    G.gemm_nt_h3(c, a, b, 1.0, 0.0, 1.0)
+    assert torch.equal(c[:96], b[:, :96].T.contiguous()) and torch.all(c[96:] == 0)
+    a = torch.randint(-8, 9, (m, k), device=G.dev()).float()
+    c0 = torch.randint(-8, 9, (m, n), device=G.dev()).float()
+    c = c0.clone()
+    G.gemm_nt_h3(c, a, b, -1.0, 1.0, 4.0)  # a power-of-two scale does not change an exact result
+    assert torch.equal(c.double(), c0.double() - a.double() @ b.double().T)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (1024, 768, 512), (2304, 2304, 1024)])
+def test_gemm_split_f16_random(m, n, k):
+    """Float32-grade accuracy of the three-product split (hi*hi + hi*lo + lo*hi, float32 accumulation) against float64,
+    with row magnitudes spread over 2^-6..1; and the lower-only form touches exactly the 128-tiles on/below the diagonal."""
+    torch.manual_seed(3)
+    scale_rows = torch.exp2(torch.randint(-6, 1, (m, 1), device=G.dev()).float())
+    a = torch.randn((m, k), device=G.dev()) * scale_rows
+    b = torch.randn((n, k), device=G.dev())
+    c0 = torch.randn((m, n), device=G.dev())
+    c = c0.clone()
+    G.gemm_nt_h3(c, a, b, -1.0, 1.0, 2.0 ** 10)
+    ref = c0.double() - a.double() @ b.double().T
+    bound = c0.abs().double() + a.abs().double() @ b.abs().double().T
+    # operand truncation 2^-22 per factor + a k-long float32 accumulation, relative to sum |terms|
+    tol = 2.0 ** -20 + 4 * (k + 1) ** 0.5 * 6e-8
+    assert ((c.double() - ref).abs() <= tol * bound).all(), ((c.double() - ref).abs() / bound).max().item()
+    if m == n:
+        c = torch.zeros((m, m), device=G.dev())
+        G.gemm_nt_h3(c, a, a, 1.0, 0.0, 2.0 ** 10, lower_only=True)
+        ref = a.double() @ a.double().T
+        idx = torch.arange(m, device=G.dev())
+        elem_lower = idx[:, None] >= idx[None, :]
+        tile_upper = (idx[:, None] // 128) < (idx[None, :] // 128)
+        bound = a.abs().double() @ a.abs().double().T
+        assert ((c.double() - ref).abs() <= tol * bound)[elem_lower].all()
+        assert torch.all(c[tile_upper] == 0)
+
+
+def test_gemm_split_f16_agrees_with_f32_mfma_in_the_cholesky():
+    """The look-ahead Cholesky with split-float16 trailing updates against the same factorisation on the float32 MFMA
+    (debug key 2 = 2): both factor the same matrix to float32 accuracy."""
+    n = 4096
+    x, y = synth.synthetic_queries(n, 32, seed=21)
+    from nngp_src_amd import _lib
+    lib = _lib.load()
+    res = {}
+    for key2 in (0, 2):
+        lib.nngp_debug_set(2, key2)
+        try:
+            mdl = GPModel(n, 32, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x / 1000.0, y)
+            res[key2] = (mdl.info(), mdl.alpha().cpu().numpy().copy())
+            mdl.close()
+        finally:
+            lib.nngp_debug_set(2, 0)
+    for key2 in (0, 2):
+        info = res[key2][0]
+        assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-9 and info["refine_iters"] <= 8, info
+    d = np.linalg.norm(res[0][1] - res[2][1]) / np.linalg.norm(res[2][1])
+    assert d < 1e-8, d  # alpha is the float64 CG answer either way
+
+
 @pytest.mark.parametrize("rows", [128, 512, 24576 + 128])  # 64x128 and 128x128 workgroup tiles
 def test_gemm_in_place_inverse_block(rows):
     torch.manual_seed(2)
