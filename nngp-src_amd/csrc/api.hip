@@ -114,7 +114,7 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
-        dev_free(split.planes); dev_free(split.counters);
+        dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
@@ -157,6 +157,13 @@ int ensure_predict_capacity(nngp_model* m, int64_t mt, bool need_ktd) {
         NNGP_TRY(dev_alloc(&m->tt_diag, cap));
         NNGP_TRY(dev_alloc(&m->b32, round_up(cap, TB) * m->np_cap));
         NNGP_TRY(dev_alloc(&m->trsm_tmp, round_up(cap, TB) * triinv_block(m->np_cap)));
+        if (m->split.planes != nullptr) {  // split copy of one right-hand-side block (float16 path of the blocked solves)
+            dev_free(m->split.planes_b); dev_free(m->split.row_inv);
+            m->split.planes_b = nullptr; m->split.row_inv = nullptr;
+            m->split.mb_cap = round_up(cap, TB);
+            NNGP_TRY(dev_alloc(&m->split.planes_b, (m->split.mb_cap + 256) * m->split.k_cap * 4));
+            NNGP_TRY(dev_alloc(&m->split.row_inv, m->split.mb_cap));
+        }
         m->m_cap = cap;
     }
     if (need_ktd && mt > m->ktd_cap) {
@@ -208,13 +215,43 @@ int ensure_lt(nngp_model* m, hipStream_t s) {
     return 0;
 }
 
-// b32 [mp, np] <- b32 (L L^T)^-1   (rows are right-hand sides)
-int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
-    if (g_debug[7] == 1) {  // timing experiment: the 128-wide recursion instead of the 1024-block form
-        NNGP_TRY(trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->np, m->dinv, m->np, s));
-        return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+// split copy of L^T by block row (operand of the "B L^-1" half on the float16 pipe); built once per fit
+int ensure_lt_split(nngp_model* m, hipStream_t s) {
+    if (m->split.lt_ready) return 0;
+    if (m->split.planes_t == nullptr) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        const int64_t ncols = (m->np_cap + m->split.k_cap - 1) / m->split.k_cap;
+        NNGP_TRY(dev_alloc(&m->split.planes_t, ncols * m->split.col_stride));
     }
-    NNGP_TRY(trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->np, m->tri, m->np, m->trsm_tmp, s));
+    NNGP_TRY(launch_split_lower_t(m->a32, m->np, m->np, m->split.k_cap, m->split.scale, m->split.planes_t,
+                                  m->split.col_stride, s));
+    m->split.lt_ready = true;
+    return 0;
+}
+
+// the factor has float16-split copies (look-ahead factorisation) and the caller did not ask for the float32 path
+bool use_split_solves(const nngp_model* m, int64_t mp) {
+    return m->split.l_ready && m->split.planes_b != nullptr && mp <= m->split.mb_cap && m->tri.bs == m->split.k_cap &&
+           g_debug[7] == 0;
+}
+
+// b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
+int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    if (g_debug[7] == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
+        return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->np, m->dinv, m->np, s);
+    if (use_split_solves(m, mp))
+        return trsm_rlt_blocks_h3(m->b32, m->np, mp, m->a32, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
+    return trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->np, m->tri, m->np, m->trsm_tmp, s);
+}
+
+// b32 [mp, np] <- b32 (L L^T)^-1
+int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    NNGP_TRY(apply_forward_f32(m, mp, s));
+    if (g_debug[7] == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+    if (use_split_solves(m, mp)) {
+        NNGP_TRY(ensure_lt_split(m, s));
+        return trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
+    }
     return trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s);
 }
 
@@ -361,9 +398,12 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     }
     if (rc == 0) rc = lookahead_create(&m->la);
     if (rc == 0 && np >= 4 * kLookAheadNb) {  // the look-ahead factorisation keeps a float16-split copy of one block column
+        // ... and keeps the copies of all block columns: the posterior's blocked triangular solves read them again
         m->split.rows_cap = np + 256;
         m->split.k_cap = kLookAheadNb;
-        rc = dev_alloc(&m->split.planes, m->split.rows_cap * m->split.k_cap * 4);
+        m->split.col_stride = m->split.rows_cap * m->split.k_cap * 4;
+        const int64_t ncols = (np + kLookAheadNb - 1) / kLookAheadNb;
+        rc = dev_alloc(&m->split.planes, ncols * m->split.col_stride);
         if (rc == 0) rc = dev_alloc(&m->split.counters, 8);
     }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
@@ -436,6 +476,7 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
+    m->split.l_ready = m->split.lt_ready = false;  // set again by the look-ahead factorisation
     return 0;
 }
 
@@ -584,7 +625,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     if (!is_ntk && m->var_refine == 0) {
         // float32 only: V^T = K_td L^-T, cov = K_tt - V^T V  (fast; error ~ cond * eps32 relative to the prior)
         NNGP_TRY(launch_convert_f64_f32(ktd, np, m->b32, np, mp, np, mp, np, s));
-        NNGP_TRY(trsm_rlt_blocks_f32(m->b32, np, mp, m->a32, np, m->tri, np, m->trsm_tmp, s));
+        NNGP_TRY(apply_forward_f32(m, mp, s));
         if (!full) return launch_row_sqsum_f32(m->b32, np, mt, np, m->tt_diag, var_or_cov, s);
         NNGP_TRY(build_ktt());
         NNGP_TRY(launch_gemm_nt_f32(m->vvt32, mp, m->b32, np, m->b32, np, mp, mp, np, 1.0f, 0.0f, false, s));

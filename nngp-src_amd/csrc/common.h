@@ -82,9 +82,13 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
 // ---- gemm_h3.hip: float32-grade products on the float16 matrix pipe (two float16 planes per operand) ----
 int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,
                       hipStream_t s);
+int launch_split_rows_rowscale(const float* src, int64_t ld_src, int64_t rows, int64_t k, float* copy_dst, int64_t ld_copy,
+                               char* out, int64_t out_ld, float* row_inv, hipStream_t s);
+int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, float scale, char* out, int64_t col_stride,
+                         hipStream_t s);
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
-                      hipStream_t s);
+                      hipStream_t s, const float* row_alpha = nullptr);
 
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
@@ -92,11 +96,17 @@ int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, fl
 int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
                  hipStream_t s);
 
-struct SplitWork {   // float16-split copy of the current block column (gemm_h3.hip); one per model
-    char* planes = nullptr;   // [rows_cap][k_cap] x 4 bytes
-    int64_t rows_cap = 0, k_cap = 0;
-    float scale = 1.0f;       // power of two, max |L_ij| * scale <= 2^14
-    int* counters = nullptr;  // 8 work counters of the persistent GEMM grid (one per XCD)
+struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one per model
+    char* planes = nullptr;    // [ncols][rows_cap][k_cap] x 4 bytes: L by block column k, row index = global row
+    int64_t rows_cap = 0, k_cap = 0, col_stride = 0;  // col_stride in bytes
+    float scale = 1.0f;        // power of two, max |L_ij| * scale <= 2^14
+    int* counters = nullptr;   // 8 work counters of the persistent GEMM grid (one per XCD)
+    bool l_ready = false;      // every block column of the current factor has been written (look-ahead factorisation)
+    char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)
+    bool lt_ready = false;
+    char* planes_b = nullptr;  // [mb_cap + 256][k_cap] x 4 bytes: the right-hand-side block of a blocked solve
+    float* row_inv = nullptr;  // [mb_cap] per-row 1/scale of planes_b
+    int64_t mb_cap = 0;
 };
 
 struct LookAhead {  // streams and events of the look-ahead Cholesky (one per model)
@@ -109,7 +119,7 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
 int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
-                        LookAhead* la, const SplitWork* sw, hipStream_t user);
+                        LookAhead* la, SplitWork* sw, hipStream_t user);
 constexpr int64_t kLookAheadNb = 1024;  // block-column width of the look-ahead Cholesky
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
                     int64_t w, hipStream_t s);
@@ -138,6 +148,11 @@ int trsm_rlt_blocks_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_
                         float* tmp, hipStream_t s);
 int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
                         float* tmp, hipStream_t s);
+// the same two solves with the large updates on the float16 pipe (split copies of L / L^T in `sw`)
+int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
+                       float* tmp, const SplitWork& sw, hipStream_t s);
+int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
+                       float* tmp, const SplitWork& sw, hipStream_t s);
 // in-place solves L x = b / L^T x = b on a float32 vector of length np
 int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);
 int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);

@@ -56,6 +56,83 @@ __global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ p,
     *reinterpret_cast<h8*>(dst + 64) = lo;
 }
 
+// One row per wave: split a float32 row with its OWN power-of-two scale (largest entry -> 2^14), write 1/scale to
+// row_inv (the GEMM epilogue multiplies it back) and, optionally, copy the float32 row to copy_dst.  Used for the
+// right-hand-side blocks of the blocked triangular solves, whose magnitudes change from sweep to sweep.
+__global__ __launch_bounds__(256) void k_split_rows_rowscale(const float* __restrict__ src, int64_t ld_src, int64_t rows,
+                                                             int k, float* __restrict__ copy_dst, int64_t ld_copy,
+                                                             char* __restrict__ out, int64_t out_ld,
+                                                             float* __restrict__ row_inv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* p = src + r * ld_src;
+    f32x4 v[4];
+    float mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k0 = 4 * (lane + 64 * i);
+        v[i] = (k0 < k) ? *reinterpret_cast<const f32x4*>(p + k0) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[i][e]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    int e2 = 0;
+    (void)frexpf(mx, &e2);  // mx = f * 2^e2, f in [0.5, 1)
+    const float sc = (mx > 0.0f && mx < 3.0e38f) ? ldexpf(1.0f, 14 - e2) : 1.0f;
+    if (lane == 0) row_inv[r] = 1.0f / sc;
+    char* o = out + r * out_ld;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k0 = 4 * (lane + 64 * i);
+        if (k0 >= k) continue;
+        if (copy_dst != nullptr) *reinterpret_cast<f32x4*>(copy_dst + r * ld_copy + k0) = v[i];
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = v[i][e] * sc;
+            const _Float16 h = (_Float16)a;
+            hi[e] = h;
+            lo[e] = (_Float16)(a - (float)h);
+        }
+        char* dst = o + (int64_t)(k0 >> 5) * 128 + (k0 & 31) * 2;
+        *reinterpret_cast<h4*>(dst) = hi;
+        *reinterpret_cast<h4*>(dst + 64) = lo;
+    }
+}
+
+// Split copy of L^T by block row: for block row j (rows [o, o+sz) of L, o = j*bs) and every column r < o,
+// out_j[r][k] = L[o + k][r] -- the operand of the "B L^-1" half of the blocked solves.  One 32 x 32 tile per workgroup
+// over the (row of L, column of L) plane, transposed through LDS; tiles on or right of the block diagonal exit.
+__global__ __launch_bounds__(256) void k_split_lower_t(const float* __restrict__ l, int64_t ld, int64_t n, int64_t bs,
+                                                       float scale, char* __restrict__ out, int64_t col_stride) {
+    __shared__ float tile[32][33];
+    const int64_t gk0 = (int64_t)blockIdx.y * 32;  // rows of L (k of the output)
+    const int64_t r0 = (int64_t)blockIdx.x * 32;   // columns of L (rows of the output)
+    const int64_t j = gk0 / bs, o = j * bs;
+    if (r0 >= o) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = l[(gk0 + ty + 8 * i) * ld + r0 + tx];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int rr = threadIdx.x >> 2, g = threadIdx.x & 3;  // output row, group of 8 k
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = tile[g * 8 + e][rr] * scale;
+            const _Float16 h = (_Float16)a;
+            hi[e] = h;
+            lo[e] = (_Float16)(a - (float)h);
+        }
+        char* dst = out + j * col_stride + (r0 + rr) * (bs * 4) + ((gk0 - o) >> 5) * 128 + g * 16;
+        *reinterpret_cast<h8*>(dst) = hi;
+        *reinterpret_cast<h8*>(dst + 64) = lo;
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -92,7 +169,7 @@ template <bool LOWER>
 __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const char* A, const char* B, int64_t ldp,
                                                     int m, int n, int tiles_m, int nk, float alpha, float beta,
                                                     int diag_shift, int order_br, int order_bc, int* counters,
-                                                    int slots_per_xcd, int ablate) {
+                                                    int slots_per_xcd, int ablate, const float* row_alpha) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * HSTAGE];
     __shared__ int s_slot;
     const int tid = threadIdx.x;
@@ -238,6 +315,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = alpha * acc[i][j][r];
+                    if (row_alpha != nullptr) v *= row_alpha[r0 + 4 * fh + (r & 3) + 8 * (r >> 2)];  // per-row operand scale
                     if (beta != 0.0f) v = fmaf(beta, cold[r], v);
                     p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
                 }
@@ -260,13 +338,37 @@ int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float
     return 0;
 }
 
+int launch_split_rows_rowscale(const float* src, int64_t ld_src, int64_t rows, int64_t k, float* copy_dst, int64_t ld_copy,
+                               char* out, int64_t out_ld, float* row_inv, hipStream_t s) {
+    if (rows <= 0) return 0;
+    NNGP_REQUIRE(k > 0 && k <= 1024 && k % 32 == 0 && ld_src % 4 == 0 && ((uintptr_t)src & 15) == 0 && out_ld >= 4 * k &&
+                     out_ld % 16 == 0 && ((uintptr_t)out & 15) == 0 && row_inv != nullptr &&
+                     (copy_dst == nullptr || (ld_copy % 4 == 0 && ((uintptr_t)copy_dst & 15) == 0)),
+                 "split_rows_rowscale: k must be a multiple of 32, at most 1024, operands 16-byte aligned");
+    hipLaunchKernelGGL(k_split_rows_rowscale, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, src, ld_src, rows, (int)k,
+                       copy_dst, ld_copy, out, out_ld, row_inv);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, float scale, char* out, int64_t col_stride,
+                         hipStream_t s) {
+    if (n <= bs) return 0;
+    NNGP_REQUIRE(n % 32 == 0 && bs % 32 == 0 && bs > 0 && ((uintptr_t)out & 15) == 0 && col_stride % 16 == 0,
+                 "split_lower_t: sizes must be multiples of 32");
+    hipLaunchKernelGGL(k_split_lower_t, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, s, l, ld, n, bs, scale,
+                       out, col_stride);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // a, b: split rows (row stride ldp bytes); rows of a / b up to the next multiple of 256 must be readable (their
 // products are never stored).  m, n multiples of 128; k a multiple of 32.  counters: 8 device ints owned by the caller
 // (zeroed here, on the stream).  reserve_cus: compute units left free for other streams (the grid is one workgroup
 // per remaining unit).
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
-                      hipStream_t s) {
+                      hipStream_t s, const float* row_alpha) {
     if (m <= 0 || n <= 0) return 0;
     NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k > 0 && k % 32 == 0 && diag_shift % 128 == 0 && diag_shift >= 0,
                  "gemm_nt_h3: m, n must be multiples of 128 and k of 32 (m=%lld n=%lld k=%lld)", (long long)m,
@@ -299,10 +401,10 @@ int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64
     if (lower_only)
         hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
                            (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters, (int)slots_per_xcd,
-                           g_debug[0] & 11);
+                           g_debug[0] & 11, row_alpha);
     else
         hipLaunchKernelGGL((k_gemm_nt_h3<false>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
-                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, g_debug[0] & 11);
+                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, g_debug[0] & 11, row_alpha);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

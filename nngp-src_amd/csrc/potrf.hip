@@ -345,14 +345,16 @@ void lookahead_destroy(LookAhead* la) {
 }
 
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
-                        LookAhead* la, const SplitWork* sw, hipStream_t user) {
+                        LookAhead* la, SplitWork* sw, hipStream_t user) {
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
     // block-column width: 1024 measured best at N = 32768 (119.4 ms; 2048: 121.3, 4096: 123.2, recursion only: 125)
     int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : kLookAheadNb;
     nb = (nb / TB) * TB;
     // large trailing updates on the float16 matrix pipe (gemm_h3.hip) unless the workspace is missing / too small or
     // debug key 2 == 2 asks for the float32-MFMA updates (A/B timing)
-    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap >= nb && sw->rows_cap >= n + 256 && g_debug[2] != 2;
+    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
+                    sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && g_debug[2] != 2;
+    if (sw != nullptr) sw->l_ready = sw->lt_ready = false;
     // (measured and dropped: inverting each diagonal block on the panel stream as it is factored -- neutral, 59.1 vs
     // 58.9 ms -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
@@ -391,10 +393,13 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // 24 -> 65.0, 48 -> 58.8, 64 -> 60.4; debug key 4 overrides)
                 const int reserve = g_debug[4] > 0 ? g_debug[4] : 32;
                 // one launch: rows [nb2, m) x columns [0, m) of the trailing matrix, on or below its diagonal
+                // (the split copy of block column k stays in place, rows at their global index: the blocked triangular
+                // solves of the posterior read it again)
                 const int64_t ldp = 4 * sw->k_cap;
-                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes, ldp, la->update);
+                char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
+                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
                 if (rc == 0)
-                    rc = launch_gemm_nt_h3(c + nb2 * ld, ld, sw->planes + nb2 * ldp, sw->planes, ldp, m - nb2, m, nbk,
+                    rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp, planes, ldp, m - nb2, m, nbk,
                                            -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, sw->counters, reserve,
                                            la->update);
             } else {
@@ -404,8 +409,13 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                     rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, nbk,
                                             -1.0f, 1.0f, true, la->update);
             }
+        } else if (rc == 0 && h3 && nbk == nb) {  // last panel: no trailing update left, but keep its split copy complete
+            const int64_t ldp = 4 * sw->k_cap;
+            rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp, ldp,
+                                   la->update);
         }
     }
+    if (rc == 0 && h3) sw->l_ready = true;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, la->panel));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, la->update));
     NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_panel_done, 0));

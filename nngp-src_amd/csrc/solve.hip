@@ -247,6 +247,58 @@ int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64
     return 0;
 }
 
+// Blocked solves with the large trailing products on the float16 pipe.  Per block column J: the diagonal solve stays a
+// float32 GEMM with the inverted block (into `tmp`); k_split_rows_rowscale copies it back and writes its split copy
+// (one power-of-two scale per right-hand-side row); the trailing update is one split-float16 launch against the
+// split copy of L (forward) or L^T (backward).  Steps whose update has too few 256 x 256 tiles to fill the GPU stay
+// on the float32 kernel (64 x 64 tiles).
+static bool h3_worth(int64_t m, int64_t cols) { return ((m + 255) / 256) * ((cols + 255) / 256) >= 96; }
+
+int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
+                       float* tmp, const SplitWork& sw, hipStream_t s) {
+    const int64_t bs = ti.bs, ldp = 4 * sw.k_cap;
+    NNGP_REQUIRE(sw.l_ready && bs == sw.k_cap && m <= sw.mb_cap, "trsm_rlt_blocks_h3: split copy of L not available");
+    for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
+        const int64_t sz = (np - o < bs) ? np - o : bs;
+        const int64_t rest = np - o - sz;
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        if (rest > 0 && sz == bs && h3_worth(m, rest)) {
+            NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s));
+            NNGP_TRY(launch_gemm_nt_h3(b + o + sz, ldb, sw.planes_b, sw.planes + j * sw.col_stride + (o + sz) * ldp, ldp, m,
+                                       rest, sz, -1.0f / sw.scale, 1.0f, false, 0, sw.counters, 0, s, sw.row_inv));
+        } else {
+            NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
+                                            hipMemcpyDeviceToDevice, s));
+            if (rest > 0)
+                NNGP_TRY(launch_gemm_nt_f32(b + o + sz, ldb, b + o, ldb, l + (o + sz) * ld + o, ld, m, rest, sz, -1.0f, 1.0f,
+                                            false, s));
+        }
+    }
+    return 0;
+}
+
+int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
+                       float* tmp, const SplitWork& sw, hipStream_t s) {
+    const int64_t bs = ti.bs, ldp = 4 * sw.k_cap;
+    NNGP_REQUIRE(sw.lt_ready && bs == sw.k_cap && m <= sw.mb_cap, "trsm_rut_blocks_h3: split copy of L^T not available");
+    const int64_t nblk = (np + bs - 1) / bs;
+    for (int64_t j = nblk - 1; j >= 0; --j) {
+        const int64_t o = j * bs;
+        const int64_t sz = (np - o < bs) ? np - o : bs;
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        if (o > 0 && sz == bs && h3_worth(m, o)) {
+            NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s));
+            NNGP_TRY(launch_gemm_nt_h3(b, ldb, sw.planes_b, sw.planes_t + j * sw.col_stride, ldp, m, o, sz, -1.0f / sw.scale,
+                                       1.0f, false, 0, sw.counters, 0, s, sw.row_inv));
+        } else {
+            NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
+                                            hipMemcpyDeviceToDevice, s));
+            if (o > 0) NNGP_TRY(launch_gemm_nt_f32(b, ldb, b + o, ldb, lt + o, ld, m, o, sz, -1.0f, 1.0f, false, s));
+        }
+    }
+    return 0;
+}
+
 // Solves L x = b in place (b, length np, float32).  Block J: x_J = X_J b_J, then b[below] -= L[below, J] x_J.
 int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s) {
     const int64_t bs = ti.bs;
