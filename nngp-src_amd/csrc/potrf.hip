@@ -352,13 +352,14 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     nb = (nb / TB) * TB;
     // large trailing updates on the float16 matrix pipe (gemm_h3.hip) unless the workspace is missing / too small or
     // debug key 2 == 2 asks for the float32-MFMA updates (A/B timing)
-    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
+    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->col_max != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
                     sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && g_debug[2] != 2;
     if (sw != nullptr) sw->l_ready = sw->lt_ready = false;
     // (measured and dropped: inverting each diagonal block on the panel stream as it is factored -- neutral, 59.1 vs
     // 58.9 ms -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
+    if (h3) NNGP_HIP_CHECK(hipMemsetAsync(sw->col_max, 0, sizeof(float) * ((n + nb - 1) / nb), user));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_in, 0));
@@ -387,7 +388,19 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         // ... then the other panel rows and the rest of the trailing matrix, overlapped with the next diagonal block
         if (rc == 0 && m > nb2) {
             rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
-            if (h3) {
+            // The leading columns of the factor are large and of one sign (K is a positive kernel); the float16 MFMA
+            // accumulator truncates toward zero, which biases long same-sign sums (-2.6e-8 relative at K = 1024 on
+            // positive data, nothing on mixed signs; float32 MFMA: 1e-10).  A coherent error of that size in the first
+            // trailing update costs two CG iterations and 40x in the refined variances, so the first `lead` columns
+            // of block column 0 go through the float32-MFMA kernels and the rest through the float16 pipe.  Measured at
+            // N = 32768 (Cholesky ms / CG iterations / level-2 variance error): lead 0: 59.8 / 7 / 1.6e-5, 128: 61.0 / 6 /
+            // 4.1e-7, 256: 61.9 / 5 / 4.0e-7, 512: 63.6 / 6, whole column: 63.6 / 5 / 4.0e-7.
+            // (debug key 3 = 10 + n: n whole block columns on float32; 20 + c: lead = 128 c)
+            const bool f32_first = !h3 || (g_debug[3] >= 10 && g_debug[3] < 20 && k < g_debug[3] - 10);
+            int64_t lead = 0;
+            if (h3 && !f32_first && k == 0) lead = (g_debug[3] >= 20 && g_debug[3] < 28) ? 128 * (int64_t)(g_debug[3] - 20) : 256;
+            if (lead > nbk - 128) lead = 0;
+            if (!f32_first) {
                 // the persistent GEMM grid leaves `reserve` compute units to the panel stream, whose small kernels
                 // otherwise queue behind 128-KB-LDS workgroups (measured at N = 32768: 0/8/16 -> 62.7 ms, 32 -> 58.7,
                 // 24 -> 65.0, 48 -> 58.8, 64 -> 60.4; debug key 4 overrides)
@@ -397,12 +410,25 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // solves of the posterior read it again)
                 const int64_t ldp = 4 * sw->k_cap;
                 char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
-                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
-                if (rc == 0)
-                    rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp, planes, ldp, m - nb2, m, nbk,
-                                           -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, sw->counters, reserve,
-                                           la->update);
+                // each block column is split with its own power-of-two scale (its measured maximum -> [2^14, 2^15))
+                if (rc == 0) rc = launch_absmax(p, ld, m, nbk, sw->col_max + k, la->update);
+                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, 1.0f, planes, ldp, la->update, sw->col_max + k);
+                if (rc == 0)  // columns [lead, nbk) of the panel (K blocks are walked from the high end down)
+                    rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp + lead * 4, planes + lead * 4, ldp, m - nb2, m,
+                                           nbk - lead, -1.0f, 1.0f, true, nb2, sw->counters, reserve, la->update, nullptr,
+                                           sw->col_max + k, sw->col_max + k);
+                if (rc == 0 && lead > 0)
+                    rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, lead, -1.0f, 1.0f, false, la->update);
+                if (rc == 0 && lead > 0)
+                    rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, lead,
+                                            -1.0f, 1.0f, true, la->update);
             } else {
+                if (h3 && rc == 0) {  // the split copy is still needed by the posterior solves
+                    const int64_t ldp = 4 * sw->k_cap;
+                    char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
+                    rc = launch_absmax(p, ld, m, nbk, sw->col_max + k, la->update);
+                    if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, 1.0f, planes, ldp, la->update, sw->col_max + k);
+                }
                 if (rc == 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
                 if (rc == 0)
@@ -411,8 +437,10 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
             }
         } else if (rc == 0 && h3 && nbk == nb) {  // last panel: no trailing update left, but keep its split copy complete
             const int64_t ldp = 4 * sw->k_cap;
-            rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp, ldp,
-                                   la->update);
+            rc = launch_absmax(p, ld, m, nbk, sw->col_max + k, la->update);
+            if (rc == 0)
+                rc = launch_split_rows(p, ld, m, nbk, 1.0f, sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp, ldp,
+                                       la->update, sw->col_max + k);
         }
     }
     if (rc == 0 && h3) sw->l_ready = true;

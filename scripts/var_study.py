@@ -10,7 +10,15 @@ from nngp_src_amd import synth
 from nngp_src_amd.model import GPModel
 
 out = {}
-for n, d, n_relu, m in [(4096, 64, 1, 512), (16384, 128, 3, 512), (32768, 128, 3, 1024)]:
+SIZES = [(4096, 64, 1, 512), (16384, 128, 3, 512), (32768, 128, 3, 1024)]
+if os.environ.get("VAR_STUDY_N"):
+    SIZES = [t for t in SIZES if t[0] == int(os.environ["VAR_STUDY_N"])]
+if os.environ.get("NNGP_DEBUG"):  # e.g. "2=2" float32-MFMA Cholesky, "7=2" float32 blocked solves
+    from nngp_src_amd import _lib
+    for kv in os.environ["NNGP_DEBUG"].split(","):
+        k, v = kv.split("=")
+        _lib.load().nngp_debug_set(int(k), int(v))
+for n, d, n_relu, m in SIZES:
     x, y = synth.synthetic_queries(n, d, seed=0); xt, _ = synth.synthetic_queries(m, d, seed=1)
     model = GPModel(n, d, [1.0] * (n_relu + 1), [0.0] * (n_relu + 1), diag_reg=1e-3, m_cap=m).fit(x, y)
     res = {}
