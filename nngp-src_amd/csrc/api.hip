@@ -114,7 +114,7 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
-        dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv); dev_free(split.col_max); dev_free(split.row_max);
+        dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
     }
@@ -223,13 +223,8 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
         const int64_t ncols = (m->np_cap + m->split.k_cap - 1) / m->split.k_cap;
         NNGP_TRY(dev_alloc(&m->split.planes_t, ncols * m->split.col_stride));
     }
-    const int64_t bs = m->split.k_cap, ncols = (m->np + bs - 1) / bs;
-    NNGP_HIP_CHECK(hipMemsetAsync(m->split.row_max, 0, sizeof(float) * ncols, s));
-    for (int64_t j = 1; j < ncols; ++j) {  // block row j: rows [j bs, ...) x columns [0, j bs)
-        const int64_t o = j * bs, sz = (m->np - o < bs) ? m->np - o : bs;
-        NNGP_TRY(launch_absmax(m->a32 + o * m->np, m->np, sz, o, m->split.row_max + j, s));
-    }
-    NNGP_TRY(launch_split_lower_t(m->a32, m->np, m->np, bs, m->split.row_max, m->split.planes_t, m->split.col_stride, s));
+    NNGP_TRY(launch_split_lower_t(m->a32, m->np, m->np, m->split.k_cap, m->split.scale, m->split.planes_t,
+                                  m->split.col_stride, s));
     m->split.lt_ready = true;
     return 0;
 }
@@ -410,8 +405,6 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         const int64_t ncols = (np + kLookAheadNb - 1) / kLookAheadNb;
         rc = dev_alloc(&m->split.planes, ncols * m->split.col_stride);
         if (rc == 0) rc = dev_alloc(&m->split.counters, 8);
-        if (rc == 0) rc = dev_alloc(&m->split.col_max, ncols);
-        if (rc == 0) rc = dev_alloc(&m->split.row_max, ncols);
     }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {
@@ -448,6 +441,12 @@ int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_
     m->trace_mean = m->pcg.host_scal[7] / (double)n;
     m->diag_max = m->pcg.host_scal[6];
     m->reg = m->absolute ? m->diag_reg : m->diag_reg * m->trace_mean;
+    {   // |L_ij| <= sqrt(max_i A_ii): scale of the float16 split copies of the factor, largest entry below 2^15
+        const double lmax = sqrt(fmax(m->diag_max, m->trace_mean) + m->reg);
+        int e = 0;
+        (void)frexp(lmax, &e);  // lmax = f * 2^e, f in [0.5, 1)
+        m->split.scale = (lmax > 0.0 && std::isfinite(lmax)) ? (float)ldexp(1.0, 15 - e) : 1.0f;
+    }
     m->have_train = true;
     return 0;
 }

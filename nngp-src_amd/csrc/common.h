@@ -80,18 +80,15 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
                                int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s);
 
 // ---- gemm_h3.hip: float32-grade products on the float16 matrix pipe (two float16 planes per operand) ----
-int launch_absmax(const float* p, int64_t ld, int64_t rows, int64_t k, float* out, hipStream_t s);  // *out zeroed by the caller
-// scale: power of two applied before the split; amax != nullptr: derived on the device from that block maximum instead
 int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,
-                      hipStream_t s, const float* amax = nullptr);
+                      hipStream_t s);
 int launch_split_rows_rowscale(const float* src, int64_t ld_src, int64_t rows, int64_t k, float* copy_dst, int64_t ld_copy,
                                char* out, int64_t out_ld, float* row_inv, hipStream_t s);
-int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, const float* row_max, char* out,
-                         int64_t col_stride, hipStream_t s);
+int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, float scale, char* out, int64_t col_stride,
+                         hipStream_t s);
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
-                      hipStream_t s, const float* row_alpha = nullptr, const float* amax_a = nullptr,
-                      const float* amax_b = nullptr);  // amax_*: device maxima of the operand blocks (their scales)
+                      hipStream_t s, const float* row_alpha = nullptr);  // row_alpha: per-row factor of the product
 
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
@@ -102,8 +99,9 @@ int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, 
 struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one per model
     char* planes = nullptr;    // [ncols][rows_cap][k_cap] x 4 bytes: L by block column k, row index = global row
     int64_t rows_cap = 0, k_cap = 0, col_stride = 0;  // col_stride in bytes
-    float* col_max = nullptr;  // [ncols] max |L_ij| of each block column's panel: its split scale (device)
-    float* row_max = nullptr;  // [ncols] the same per block row, for planes_t
+    float scale = 1.0f;        // power of two with max |L_ij| * scale < 2^15: |L_ij| <= sqrt(max_i A_ii).  (A scale per
+                               // block column from its measured maximum changed nothing: the float16 pipe keeps
+                               // subnormal low planes exact; accuracy is limited by accumulator truncation instead.)
     int* counters = nullptr;   // 8 work counters of the persistent GEMM grid (one per XCD)
     bool l_ready = false;      // every block column of the current factor has been written (look-ahead factorisation)
     char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)

@@ -34,41 +34,9 @@ constexpr int HSTAGE = 2 * HT * HROW;      // A rows + B rows
 
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * HROW + ((ch ^ ((row >> 1) & 7)) << 4); }
 
-// power-of-two scale that puts the largest magnitude `mx` of an operand block into [2^14, 2^15) (float16 max 65504)
-__device__ __forceinline__ float scale_from_max(float mx) {
-    int e = 0;
-    (void)frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
-    return (mx > 0.0f && mx < 3.0e38f) ? ldexpf(1.0f, 15 - e) : 1.0f;
-}
-
-// max |p_ij| over a [rows, k] block into *out (atomic max on the bits of a non-negative float; *out zeroed by the
-// caller).  Block columns of the factor shrink by ~2^5 from the first to the later ones, so each gets its own scale.
-__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ p, int64_t ld, int64_t rows, int k4_per_row,
-                                                float* __restrict__ out) {
-    __shared__ float red[4];
-    const int64_t total = rows * k4_per_row;
-    float mx = 0.0f;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t r = idx / k4_per_row;
-        const int c4 = (int)(idx % k4_per_row);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + r * ld + (int64_t)c4 * 4);
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(mx));
-    }
-}
-
 // float32 rows -> split rows.  One thread per 8 consecutive k of one row.
 __global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ p, int64_t ld, int64_t rows, int k8_per_row,
-                                                    float scale, const float* __restrict__ amax, char* __restrict__ out,
-                                                    int64_t out_ld) {
-    if (amax != nullptr) scale = scale_from_max(*amax);  // scale from the block's measured maximum (device scalar)
+                                                    float scale, char* __restrict__ out, int64_t out_ld) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = idx / k8_per_row;
     const int c8 = (int)(idx % k8_per_row);
@@ -139,14 +107,12 @@ __global__ __launch_bounds__(256) void k_split_rows_rowscale(const float* __rest
 // out_j[r][k] = L[o + k][r] -- the operand of the "B L^-1" half of the blocked solves.  One 32 x 32 tile per workgroup
 // over the (row of L, column of L) plane, transposed through LDS; tiles on or right of the block diagonal exit.
 __global__ __launch_bounds__(256) void k_split_lower_t(const float* __restrict__ l, int64_t ld, int64_t n, int64_t bs,
-                                                       const float* __restrict__ row_max, char* __restrict__ out,
-                                                       int64_t col_stride) {
+                                                       float scale, char* __restrict__ out, int64_t col_stride) {
     __shared__ float tile[32][33];
     const int64_t gk0 = (int64_t)blockIdx.y * 32;  // rows of L (k of the output)
     const int64_t r0 = (int64_t)blockIdx.x * 32;   // columns of L (rows of the output)
     const int64_t j = gk0 / bs, o = j * bs;
     if (r0 >= o) return;
-    const float scale = scale_from_max(row_max[j]);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = l[(gk0 + ty + 8 * i) * ld + r0 + tx];
@@ -203,11 +169,7 @@ template <bool LOWER>
 __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const char* A, const char* B, int64_t ldp,
                                                     int m, int n, int tiles_m, int nk, float alpha, float beta,
                                                     int diag_shift, int order_br, int order_bc, int* counters,
-                                                    int slots_per_xcd, int ablate, const float* row_alpha,
-                                                    const float* amax_a, const float* amax_b) {
-    // operand scales measured on the device (block maxima): the product is divided by them
-    if (amax_a != nullptr) alpha /= scale_from_max(*amax_a);
-    if (amax_b != nullptr) alpha /= scale_from_max(*amax_b);
+                                                    int slots_per_xcd, int ablate, const float* row_alpha) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * HSTAGE];
     __shared__ int s_slot;
     const int tid = threadIdx.x;
@@ -363,26 +325,15 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const
 
 }  // namespace
 
-int launch_absmax(const float* p, int64_t ld, int64_t rows, int64_t k, float* out, hipStream_t s) {
-    if (rows <= 0 || k <= 0) return 0;
-    NNGP_REQUIRE(k % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0 && out != nullptr, "absmax: operands must be 16-byte aligned");
-    const int64_t total = rows * (k / 4);
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, p, ld, rows, (int)(k / 4), out);
-    NNGP_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,
-                      hipStream_t s, const float* amax) {
+                      hipStream_t s) {
     if (rows <= 0) return 0;
     NNGP_REQUIRE(k > 0 && k % 32 == 0 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
                      out_ld >= 4 * k && out_ld % 16 == 0,
                  "split_rows: k must be a multiple of 32 and the operands 16-byte aligned");
     const int64_t total = rows * (k / 8);
     hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, ld, rows, (int)(k / 8),
-                       scale, amax, out, out_ld);
+                       scale, out, out_ld);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -400,12 +351,12 @@ int launch_split_rows_rowscale(const float* src, int64_t ld_src, int64_t rows, i
     return 0;
 }
 
-int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, const float* row_max, char* out,
-                         int64_t col_stride, hipStream_t s) {
+int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, float scale, char* out, int64_t col_stride,
+                         hipStream_t s) {
     if (n <= bs) return 0;
     NNGP_REQUIRE(n % 32 == 0 && bs % 32 == 0 && bs > 0 && ((uintptr_t)out & 15) == 0 && col_stride % 16 == 0,
                  "split_lower_t: sizes must be multiples of 32");
-    hipLaunchKernelGGL(k_split_lower_t, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, s, l, ld, n, bs, row_max,
+    hipLaunchKernelGGL(k_split_lower_t, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, s, l, ld, n, bs, scale,
                        out, col_stride);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -417,7 +368,7 @@ int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, cons
 // per remaining unit).
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
-                      hipStream_t s, const float* row_alpha, const float* amax_a, const float* amax_b) {
+                      hipStream_t s, const float* row_alpha) {
     if (m <= 0 || n <= 0) return 0;
     NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k > 0 && k % 32 == 0 && diag_shift % 128 == 0 && diag_shift >= 0,
                  "gemm_nt_h3: m, n must be multiples of 128 and k of 32 (m=%lld n=%lld k=%lld)", (long long)m,
@@ -450,10 +401,10 @@ int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64
     if (lower_only)
         hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
                            (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters, (int)slots_per_xcd,
-                           g_debug[0] & 11, row_alpha, amax_a, amax_b);
+                           g_debug[0] & 11, row_alpha);
     else
         hipLaunchKernelGGL((k_gemm_nt_h3<false>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
-                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, g_debug[0] & 11, row_alpha, amax_a, amax_b);
+                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, g_debug[0] & 11, row_alpha);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -352,14 +352,13 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     nb = (nb / TB) * TB;
     // large trailing updates on the float16 matrix pipe (gemm_h3.hip) unless the workspace is missing / too small or
     // debug key 2 == 2 asks for the float32-MFMA updates (A/B timing)
-    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->col_max != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
+    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
                     sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && g_debug[2] != 2;
     if (sw != nullptr) sw->l_ready = sw->lt_ready = false;
     // (measured and dropped: inverting each diagonal block on the panel stream as it is factored -- neutral, 59.1 vs
     // 58.9 ms -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
-    if (h3) NNGP_HIP_CHECK(hipMemsetAsync(sw->col_max, 0, sizeof(float) * ((n + nb - 1) / nb), user));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_in, 0));
@@ -410,13 +409,11 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // solves of the posterior read it again)
                 const int64_t ldp = 4 * sw->k_cap;
                 char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
-                // each block column is split with its own power-of-two scale (its measured maximum -> [2^14, 2^15))
-                if (rc == 0) rc = launch_absmax(p, ld, m, nbk, sw->col_max + k, la->update);
-                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, 1.0f, planes, ldp, la->update, sw->col_max + k);
+                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
                 if (rc == 0)  // columns [lead, nbk) of the panel (K blocks are walked from the high end down)
                     rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp + lead * 4, planes + lead * 4, ldp, m - nb2, m,
-                                           nbk - lead, -1.0f, 1.0f, true, nb2, sw->counters, reserve, la->update, nullptr,
-                                           sw->col_max + k, sw->col_max + k);
+                                           nbk - lead, -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, sw->counters, reserve,
+                                           la->update);
                 if (rc == 0 && lead > 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, lead, -1.0f, 1.0f, false, la->update);
                 if (rc == 0 && lead > 0)
@@ -426,8 +423,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 if (h3 && rc == 0) {  // the split copy is still needed by the posterior solves
                     const int64_t ldp = 4 * sw->k_cap;
                     char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
-                    rc = launch_absmax(p, ld, m, nbk, sw->col_max + k, la->update);
-                    if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, 1.0f, planes, ldp, la->update, sw->col_max + k);
+                    rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
                 }
                 if (rc == 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
@@ -437,10 +433,8 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
             }
         } else if (rc == 0 && h3 && nbk == nb) {  // last panel: no trailing update left, but keep its split copy complete
             const int64_t ldp = 4 * sw->k_cap;
-            rc = launch_absmax(p, ld, m, nbk, sw->col_max + k, la->update);
-            if (rc == 0)
-                rc = launch_split_rows(p, ld, m, nbk, 1.0f, sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp, ldp,
-                                       la->update, sw->col_max + k);
+            rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp, ldp,
+                                   la->update);
         }
     }
     if (rc == 0 && h3) sw->l_ready = true;

@@ -265,7 +265,7 @@ int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t
         if (rest > 0 && sz == bs && h3_worth(m, rest)) {
             NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s));
             NNGP_TRY(launch_gemm_nt_h3(b + o + sz, ldb, sw.planes_b, sw.planes + j * sw.col_stride + (o + sz) * ldp, ldp, m,
-                                       rest, sz, -1.0f, 1.0f, false, 0, sw.counters, 0, s, sw.row_inv, nullptr, sw.col_max + j));
+                                       rest, sz, -1.0f / sw.scale, 1.0f, false, 0, sw.counters, 0, s, sw.row_inv));
         } else {
             NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
                                             hipMemcpyDeviceToDevice, s));
@@ -288,8 +288,8 @@ int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_
         NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
         if (o > 0 && sz == bs && h3_worth(m, o)) {
             NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s));
-            NNGP_TRY(launch_gemm_nt_h3(b, ldb, sw.planes_b, sw.planes_t + j * sw.col_stride, ldp, m, o, sz, -1.0f, 1.0f, false,
-                                       0, sw.counters, 0, s, sw.row_inv, nullptr, sw.row_max + j));
+            NNGP_TRY(launch_gemm_nt_h3(b, ldb, sw.planes_b, sw.planes_t + j * sw.col_stride, ldp, m, o, sz, -1.0f / sw.scale, 1.0f,
+                                       false, 0, sw.counters, 0, s, sw.row_inv));
         } else {
             NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
                                             hipMemcpyDeviceToDevice, s));
