@@ -101,6 +101,14 @@ int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_
 int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, void* stream);
 int nngp_model_factor(nngp_model* m, void* stream);
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream);
+/* Appends b training rows (device pointers x_new [b, d], y_new [b, ny]) to a fitted model: the kernel rows of the new
+ * queries are built and the float32 factor is EXTENDED (L10 by a blocked triangular solve against the existing factor,
+ * L11 by a small Cholesky) instead of refactored -- the active-learning loop of the reference
+ * (active/ActiveLearner.py:43-77) refits from scratch after every batch of `budget` queries.  n + b <= n_cap.
+ * Follow with nngp_model_solve: alpha is the exact float64 solution for all n + b rows (the extended factor is the
+ * CG preconditioner; with a relative regulariser its old part belongs to the previous trace, which costs no accuracy). */
+int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, int64_t b, void* stream);
+
 
 /* Block-column pieces of `factor` for the multi-GPU right-looking Cholesky (host: nngp-src_amd/distributed.py):
  * block columns of width w (multiple of 128) are dealt cyclically to the ranks; the owner factors its column

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "nngp_version", "nngp_debug_set", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
-    "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_kernel_buffer", "nngp_model_info",
+    "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_append", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode",
@@ -86,6 +86,7 @@ def load():
     lib.nngp_encoder_dim.argtypes = [vp]
     lib.nngp_encoder_encode.argtypes = [vp, ctypes.c_char_p, i64, i32, vp, vp, i64, ctypes.POINTER(i64)]
     lib.nngp_model_set_refine.argtypes = [vp, i32]
+    lib.nngp_model_append.argtypes = [vp, vp, vp, i64, vp]
     lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.nngp_gemm_nt_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float, i32, vp]

@@ -59,6 +59,7 @@ struct nngp_model {
     int absolute = 0;
 
     int64_t n = 0, np = 0;
+    int64_t ld = 0;  // leading dimension of k64 / a32 = np_cap, fixed so that rows can be appended in place
     bool have_train = false, built = false, factored = false, solved = false;
 
     // training-side buffers
@@ -209,7 +210,7 @@ int ensure_lt(nngp_model* m, hipStream_t s) {
         NNGP_TRY(dev_alloc(&m->lt32, m->np_cap * m->np_cap));
         NNGP_TRY(dev_alloc(&m->dinvt, (m->np_cap / TB) * TB * TB));
     }
-    NNGP_TRY(launch_transpose_f32(m->a32, m->np, m->lt32, m->np, m->np, s));
+    NNGP_TRY(launch_transpose_f32(m->a32, m->ld, m->lt32, m->np, m->np, s));
     NNGP_TRY(launch_transpose_blocks_f32(m->dinv, m->dinvt, TB, m->np / TB, s));
     m->lt_ready = true;
     return 0;
@@ -223,7 +224,7 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
         const int64_t ncols = (m->np_cap + m->split.k_cap - 1) / m->split.k_cap;
         NNGP_TRY(dev_alloc(&m->split.planes_t, ncols * m->split.col_stride));
     }
-    NNGP_TRY(launch_split_lower_t(m->a32, m->np, m->np, m->split.k_cap, m->split.scale, m->split.planes_t,
+    NNGP_TRY(launch_split_lower_t(m->a32, m->ld, m->np, m->split.k_cap, m->split.scale, m->split.planes_t,
                                   m->split.col_stride, s));
     m->split.lt_ready = true;
     return 0;
@@ -238,10 +239,10 @@ bool use_split_solves(const nngp_model* m, int64_t mp) {
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
 int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     if (g_debug[7] == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
-        return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->np, m->dinv, m->np, s);
+        return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->ld, m->dinv, m->np, s);
     if (use_split_solves(m, mp))
-        return trsm_rlt_blocks_h3(m->b32, m->np, mp, m->a32, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
-    return trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->np, m->tri, m->np, m->trsm_tmp, s);
+        return trsm_rlt_blocks_h3(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, m->split, s);
+    return trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, s);
 }
 
 // b32 [mp, np] <- b32 (L L^T)^-1
@@ -263,7 +264,7 @@ int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps,
     NNGP_TRY(apply_inverse_f32(m, mp, s));
     NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));
     for (int it = 0; it < sweeps + (final_residual ? 1 : 0); ++it) {
-        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, rhs, np, m->z64, np, m->k64, np, mp, np, np, -1.0, 1.0, s));
+        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, rhs, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
         NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
         if (it == sweeps) break;
         NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
@@ -376,6 +377,7 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         return rc;
     }
     m->n_cap = n_cap; m->np_cap = round_up(n_cap, TB); m->m_cap = 0;
+    m->ld = m->np_cap;
     m->d = d; m->ny = ny; m->get = get; m->diag_reg = diag_reg; m->absolute = diag_reg_absolute_scale;
     const int64_t np = m->np_cap;
     auto A = [&](int r) { if (rc == 0) rc = r; };
@@ -460,10 +462,10 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     a.n1 = m->n; a.n2 = m->n; a.d = m->d;
     a.row_begin = row_begin; a.row_end = row_end;
     a.sym = (row_begin == 0 && row_end == m->n) ? 1 : 0;
-    a.ld64 = a.ld32 = m->np;
+    a.ld64 = a.ld32 = m->ld;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
     NNGP_TRY(launch_kernel_build(a, m->arch, s));
-    NNGP_TRY(launch_zero_pad_f64(m->k64, m->np, m->n, m->np, s));  // float64 GEMMs read the padded matrix
+    NNGP_TRY(launch_zero_pad_f64(m->k64, m->ld, m->n, m->np, s));  // float64 GEMMs read the padded matrix
     m->built = true;  // the caller vouches for the remaining rows (all-gather) before factor
     m->factored = m->solved = false;
     return 0;
@@ -472,7 +474,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
 int nngp_model_factor_begin(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
-    NNGP_TRY(launch_factor_input(m->k64, m->np, m->a32, m->np, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
+    NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
@@ -483,21 +485,21 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
 int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* stream) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor_panel: build the kernel rows first");
     // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
-    return potrf_panel_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), col0, width,
+    return potrf_panel_f32(m->a32, m->np, m->ld, m->dinv, m->clamped, (float)(0.25 * m->reg), col0, width,
                            (hipStream_t)stream);
 }
 
 int nngp_model_factor_update(nngp_model* m, int64_t panel_col0, int64_t panel_width, int64_t col0, int64_t width,
                              void* stream) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor_update: build the kernel rows first");
-    return potrf_update_f32(m->a32, m->np, m->np, panel_col0, panel_width, col0, width, (hipStream_t)stream);
+    return potrf_update_f32(m->a32, m->np, m->ld, panel_col0, panel_width, col0, width, (hipStream_t)stream);
 }
 
 int nngp_model_factor_end(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor_end: build the kernel rows first");
     m->tri.bs = triinv_block(m->np);
-    NNGP_TRY(triinv_build(m->a32, m->np, m->dinv, m->np, m->tri, s));
+    NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
     m->factored = true;
     m->solved = false;
     m->lt_ready = false;
@@ -508,7 +510,7 @@ int nngp_model_factor_end(nngp_model* m, void* stream) {
 int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv) {
     NNGP_REQUIRE(m != nullptr && m->have_train, "factor_buffers: call set_train first");
     if (a32) *a32 = m->a32;
-    if (ld) *ld = m->np;
+    if (ld) *ld = m->ld;
     if (dinv) *dinv = m->dinv;
     return 0;
 }
@@ -516,8 +518,83 @@ int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** d
 int nngp_model_factor(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_TRY(nngp_model_factor_begin(m, stream));
-    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->np, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, &m->split, s));
+    NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->ld, m->dinv, m->clamped, (float)(0.25 * m->reg), m->la, &m->split, s));
     return nngp_model_factor_end(m, stream);
+}
+
+// Appends b training rows to a fitted model without refactoring what is already there (the
+// reference's active-learning loop refits from scratch, ActiveLearner.py:43-77).  With r0 = the last 128-aligned row
+// count of the old fit:  kernel rows [n, n+b) are built against all rows and mirrored into the old rows' columns;
+//   L10 = A[r0:, :r0] L00^-T  (blocked triangular solve with the old factor's inverted 1024-blocks),
+//   L11 = chol(A[r0:, r0:] - L10 L10^T)  (SYRK + blocked Cholesky of the small trailing block).
+// The relative regulariser changes with the trace, so L00 is the factor of the OLD A00 -- it is only the CG
+// preconditioner; alpha and the refined covariances are computed against the float64 kernel with the new reg.
+// Call nngp_model_solve afterwards.  Cost ~ b N^2 instead of N^3 / 3.
+int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, int64_t b, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->factored, "append: fit the model first");
+    NNGP_REQUIRE(x_new != nullptr && y_new != nullptr && b > 0, "append: bad arguments");
+    NNGP_REQUIRE(m->n + b <= m->n_cap, "append: %lld + %lld rows exceed n_cap = %lld", (long long)m->n, (long long)b,
+                 (long long)m->n_cap);
+    const int64_t n0 = m->n, n1 = n0 + b, np0 = m->np, np1 = round_up(n1, TB), r0 = (n0 / TB) * TB, rows = np1 - r0;
+    NNGP_REQUIRE(r0 > 0, "append: the fitted model must have at least 128 rows");
+    NNGP_TRY(ensure_predict_capacity(m, rows, false));  // b32 / trsm_tmp workspace of the blocked solve
+    // 1. data, diagonal, regulariser
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->x + n0 * m->d, x_new, sizeof(double) * b * m->d, hipMemcpyDeviceToDevice, s));
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->y + n0 * m->ny, y_new, sizeof(double) * b * m->ny, hipMemcpyDeviceToDevice, s));
+    NNGP_TRY(launch_row_sqnorm(m->x + n0 * m->d, b, m->d, m->q + n0, s));
+    NNGP_TRY(launch_diag_from_q(m->q + n0, b, m->arch, m->get == NNGP_GET_NNGP ? m->kdiag + n0 : nullptr,
+                                m->get == NNGP_GET_NTK ? m->kdiag + n0 : nullptr, s));
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, m->kdiag, n1, m->pcg.scal + 6);
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->pcg.host_scal + 6, m->pcg.scal + 6, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    NNGP_HIP_CHECK(hipStreamSynchronize(s));
+    m->trace_mean = m->pcg.host_scal[7] / (double)n1;
+    m->diag_max = m->pcg.host_scal[6];
+    m->reg = m->absolute ? m->diag_reg : m->diag_reg * m->trace_mean;
+    const float old_scale = m->split.scale;
+    {
+        const double lmax = sqrt(fmax(m->diag_max, m->trace_mean) + m->reg);
+        int e = 0;
+        (void)frexp(lmax, &e);
+        m->split.scale = (lmax > 0.0 && std::isfinite(lmax)) ? (float)ldexp(1.0, 15 - e) : 1.0f;
+    }
+    m->n = n1;
+    m->np = np1;
+    m->solved = false;
+    // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
+    BuildArgs a{};
+    a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
+    a.n1 = n1; a.n2 = n1; a.d = m->d;
+    a.row_begin = n0; a.row_end = n1; a.sym = 0;
+    a.ld64 = a.ld32 = m->ld;
+    if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
+    NNGP_TRY(launch_kernel_build(a, m->arch, s));
+    NNGP_TRY(launch_mirror_rows_f64(m->k64, m->ld, n0, n1, s));
+    NNGP_TRY(launch_zero_pad_f64(m->k64, m->ld, n1, np1, s));
+    // 3. factor rows [r0, np1)
+    NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, n1, np1, m->reg, m->reg + m->trace_mean, s, r0));
+    float* a10 = m->a32 + r0 * m->ld;
+    NNGP_TRY(trsm_rlt_blocks_f32(a10, m->ld, rows, m->a32, m->ld, m->tri, r0, m->trsm_tmp, s));
+    NNGP_TRY(launch_gemm_nt_f32(a10 + r0, m->ld, a10, m->ld, a10, m->ld, rows, rows, r0, -1.0f, 1.0f, true, s));
+    NNGP_TRY(potrf_f32(a10 + r0, rows, m->ld, m->dinv + (r0 / TB) * TB * TB, m->clamped, (float)(0.25 * m->reg), s));
+    m->tri.bs = triinv_block(m->np);
+    NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
+    // 4. float16-split copies: rows >= r0 of every block column (same scale as the rest), L^T copies rebuilt lazily
+    if (m->split.l_ready && m->split.scale == old_scale && m->split.rows_cap >= np1 + 256) {
+        const int64_t bs = m->split.k_cap, ldp = 4 * bs;
+        for (int64_t j = 0, o = 0; o + bs < np1; ++j, o += bs) {
+            const int64_t first = (o + bs > r0) ? o + bs : r0;  // rows below the diagonal block, from r0 on
+            NNGP_TRY(launch_split_rows(m->a32 + first * m->ld + o, m->ld, np1 - first, bs, m->split.scale,
+                                       m->split.planes + j * m->split.col_stride + first * ldp, ldp, s));
+        }
+    } else {
+        m->split.l_ready = false;
+    }
+    m->split.lt_ready = false;
+    m->lt_ready = false;
+    m->aux_ready = false;
+    (void)np0;
+    return 0;
 }
 
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {
@@ -531,7 +608,7 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
         NNGP_TRY(launch_strided_copy_f64(m->y + c, m->ny, m->pcg.bcol, 1, m->n, s));
         int it = 0;
         double rr = 0.0;
-        NNGP_TRY(pcg_solve(m->k64, m->np, m->n, m->reg, m->a32, m->np, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
+        NNGP_TRY(pcg_solve(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
                            m->pcg, max_iters, tol, &it, &rr, s));
         NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
         if (it > m->iters) m->iters = it;
@@ -551,7 +628,7 @@ int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, v
 int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld) {
     NNGP_REQUIRE(m != nullptr && m->have_train, "kernel_buffer: call set_train first");
     if (k64) *k64 = m->k64;
-    if (ld) *ld = m->np;
+    if (ld) *ld = m->ld;
     return 0;
 }
 
@@ -594,7 +671,8 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     if (mt == 0) return 0;
     const bool is_ntk = (m->get == NNGP_GET_NTK);
     const int64_t n = m->n, np = m->np, mp = round_up(mt, TB);
-    NNGP_TRY(ensure_predict_capacity(m, mt, !on_train));
+    const bool compact_train = on_train && m->ld != m->np;  // K_dd rows have stride ld: copy them to the compact cross buffer
+    NNGP_TRY(ensure_predict_capacity(m, mt, !on_train || compact_train));
 
     // ---- cross kernel of `get` and the mean: mu = K_td alpha (float64) ----
     const double* xt = on_train ? m->x : x_test;
@@ -604,6 +682,12 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(launch_row_sqnorm(xt, mt, m->d, m->xt_q, s));
         qt = m->xt_q;
         NNGP_TRY(build_cross(m, xt, qt, mt, mp, !is_ntk, m->ktd64, s));
+        ktd = m->ktd64;
+    }
+    if (compact_train) {
+        NNGP_HIP_CHECK(hipMemsetAsync(m->ktd64, 0, sizeof(double) * mp * np, s));
+        NNGP_HIP_CHECK(hipMemcpy2DAsync(m->ktd64, sizeof(double) * np, m->k64, sizeof(double) * m->ld, sizeof(double) * np, mt,
+                                        hipMemcpyDeviceToDevice, s));
         ktd = m->ktd64;
     }
     for (int c = 0; c < m->ny; ++c)

@@ -174,7 +174,8 @@ int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float*
 int launch_convert_f64_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
                            int64_t rows_p, int64_t cols_p, hipStream_t s);
 int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np,
-                        double reg, double pad_diag, hipStream_t s);
+                        double reg, double pad_diag, hipStream_t s, int64_t row_begin = 0);
+int launch_mirror_rows_f64(double* k, int64_t ld, int64_t n0, int64_t n1, hipStream_t s);
 int launch_row_sqsum_f32(const float* v, int64_t ld, int64_t rows, int64_t cols, const double* base,
                          double* out, hipStream_t s);
 int launch_cov_finish(const double* ktt, int64_t ldk, const float* vvt, int64_t ldv, int64_t m, double* cov,

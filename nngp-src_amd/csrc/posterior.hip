@@ -160,11 +160,37 @@ __global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__
 
 }  // namespace
 
+// K[j, i] = K[i, j] for i in [n0, n1), j in [0, n0): the columns of the old rows for newly appended rows (32x32 tiles)
+__global__ __launch_bounds__(256) void k_mirror_rows_f64(double* __restrict__ k, int64_t ld, int64_t n0, int64_t n1) {
+    __shared__ double tile[32][33];
+    const int64_t i0 = n0 + (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t i = i0 + ty + 8 * e, j = j0 + tx;
+        tile[ty + 8 * e][tx] = (i < n1 && j < n0) ? k[i * ld + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t j = j0 + ty + 8 * e, i = i0 + tx;
+        if (i < n1 && j < n0) k[j * ld + i] = tile[tx][ty + 8 * e];
+    }
+}
+
+int launch_mirror_rows_f64(double* k, int64_t ld, int64_t n0, int64_t n1, hipStream_t s) {
+    if (n1 <= n0 || n0 <= 0) return 0;
+    hipLaunchKernelGGL(k_mirror_rows_f64, dim3((unsigned)((n0 + 31) / 32), (unsigned)((n1 - n0 + 31) / 32)), dim3(256), 0, s, k,
+                       ld, n0, n1);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np, double reg,
-                        double pad_diag, hipStream_t s) {
-    NNGP_REQUIRE(np % TB == 0 && np <= 65535LL * 1024, "factor_input: bad padded size %lld", (long long)np);
+                        double pad_diag, hipStream_t s, int64_t row_begin) {
+    NNGP_REQUIRE(np % TB == 0 && np <= 65535LL * 1024 && row_begin >= 0, "factor_input: bad padded size %lld", (long long)np);
     // grid.y is limited to 65535 rows per launch
-    for (int64_t r0 = 0; r0 < np; r0 += 65535) {
+    for (int64_t r0 = row_begin; r0 < np; r0 += 65535) {
         const int64_t rows = (np - r0 < 65535) ? np - r0 : 65535;
         hipLaunchKernelGGL(k_factor_input, dim3((unsigned)((np + 1023) / 1024), (unsigned)rows), dim3(256), 0, s,
                            k64, ld64, a32, ld32, n, np, reg, pad_diag, r0);

@@ -60,6 +60,24 @@ class GPModel:
         self._keep = [xd, yd]
         _lib.check(self.lib.nngp_model_set_train(self.handle, _lib.ptr(xd), _lib.ptr(yd), self.n, _lib.stream_ptr()))
 
+    def append(self, x_new, y_new, solve: bool = True):
+        """Add training rows to a fitted model: their kernel rows are built and the factor is extended in place
+        (``nngp_model_append``: cost ~ b N^2 instead of a full N^3/3 refit), then alpha is re-solved."""
+        xd = _lib.to_device_f64(x_new, self.device)
+        yd = _lib.to_device_f64(y_new, self.device).reshape(xd.shape[0], -1)
+        if xd.ndim != 2 or xd.shape[1] != self.d or yd.shape[1] != self.ny:
+            raise ValueError("append: x_new must be [b, %d] and y_new [b, %d]" % (self.d, self.ny))
+        b = int(xd.shape[0])
+        if b == 0:
+            return self
+        if self.n + b > self.n_cap:
+            raise ValueError("append: %d + %d rows exceed the capacity %d" % (self.n, b, self.n_cap))
+        _lib.check(self.lib.nngp_model_append(self.handle, _lib.ptr(xd), _lib.ptr(yd), b, _lib.stream_ptr()))
+        self.n += b
+        if solve:
+            self.solve()
+        return self
+
     def build_rows(self, row_begin: int = 0, row_end: int = None):
         row_end = self.n if row_end is None else row_end
         _lib.check(self.lib.nngp_model_build_rows(self.handle, int(row_begin), int(row_end), _lib.stream_ptr()))
@@ -85,8 +103,8 @@ class GPModel:
         """(a32 [np, np] float32 view, dinv [np/128, 128, 128] float32 view) of the library-owned factor buffers."""
         a, ld, d = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p()
         _lib.check(self.lib.nngp_model_factor_buffers(self.handle, ctypes.byref(a), ctypes.byref(ld), ctypes.byref(d)))
-        np_ = ld.value
-        a32 = _wrap_device(a.value, np_ * np_, self.device, "<f4").view(np_, np_)
+        np_ = self.info()["n_padded"]  # rows/columns in use; the row stride ld is the padded capacity
+        a32 = _wrap_device(a.value, np_ * ld.value, self.device, "<f4").view(np_, ld.value)[:, :np_]
         dinv = _wrap_device(d.value, (np_ // 128) * 128 * 128, self.device, "<f4").view(np_ // 128, 128, 128)
         return a32, dinv
 

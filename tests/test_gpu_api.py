@@ -6,11 +6,13 @@ import types
 
 import numpy as np
 import pytest
+import torch
 
 import nngp_oracle as o
 import nngp_src_amd as nt
 from nngp_src_amd import encoder as enc, stax, synth, train as train_cli
 from nngp_src_amd.estimator import Estimator
+from nngp_src_amd.model import GPModel
 
 import gpu_util as G
 
@@ -145,3 +147,33 @@ def test_active_learning_loop(golden_dir):
         pf = learner2.train(kernel_fn, Xtr, Ytr)
     got = set(learner2.active_test(pf, Xpool).tolist())
     assert len(got ^ want) <= 2  # identical up to ties at the selection boundary
+
+
+@pytest.mark.parametrize("n0,b,ncap", [(1500, 700, 2200), (4200, 1000, 6000), (4096, 128, 4224)])
+def test_append_rows_matches_full_refit(n0, b, ncap):
+    """nngp_model_append: extending the factor (L10 by a blocked solve, L11 by a small Cholesky) gives the same
+    float64 alpha and posterior as a full refit on the concatenated training set; twice in a row for the middle case."""
+    d = 24
+    x, y = synth.synthetic_queries(ncap, d, seed=3)
+    xt, _ = synth.synthetic_queries(200, d, seed=4)
+    w, bb = [1.0, 1.0], [0.0, 0.0]
+    steps = [n0, n0 + b] + ([ncap] if n0 + b < ncap else [])
+    inc = GPModel(ncap, d, w, bb, diag_reg=1e-3).fit(x[:n0], y[:n0])
+    for prev, cur in zip(steps[:-1], steps[1:]):
+        inc.append(x[prev:cur], y[prev:cur])
+        info = inc.info()
+        assert info["n"] == cur and info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-9 and info["refine_iters"] <= 10, info
+        ref = GPModel(cur, d, w, bb, diag_reg=1e-3).fit(x[:cur], y[:cur])
+        a_inc, a_ref = inc.alpha().cpu().numpy(), ref.alpha().cpu().numpy()
+        assert np.linalg.norm(a_inc - a_ref) <= 1e-7 * np.linalg.norm(a_ref)
+        m_inc, v_inc = inc.predict(xt, cov="diag")
+        m_ref, v_ref = ref.predict(xt, cov="diag")
+        assert np.allclose(m_inc, m_ref, rtol=1e-8, atol=1e-8 * np.abs(m_ref).max())
+        assert np.allclose(v_inc, v_ref, rtol=1e-5, atol=1e-9 * np.abs(v_ref).max())
+        # the train-train kernel in HBM is the full symmetric matrix of the concatenated set
+        k_inc, ld = inc.kernel_buffer()
+        k_ref, ld_ref = ref.kernel_buffer()
+        assert torch.allclose(k_inc[:cur, :cur], k_ref[:cur, :cur], rtol=1e-13, atol=0.0)  # (row build vs mirrored tiles)
+        assert torch.equal(k_inc[:cur, :cur], k_inc[:cur, :cur].T)
+        ref.close()
+    inc.close()
