@@ -222,6 +222,8 @@ def main():
                          "north_star_frac_build_plus_cholesky": round((fl["kernel_build"] + fl["cholesky"]) /
                                                                        ((st["kernel_build"] + st["cholesky"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "stages_ms": {k: round(v, 3) for k, v in st.items()},
+            "stages_note": "the CG solve for alpha is deferred to the posterior stage, where it runs on its own stream under the "
+                           "covariance products (alpha_solve only records the request)",
             "fit_info": {"cg_iters": info["refine_iters"], "rel_residual": info["rel_residual"],
                          "clamped_pivots": info["clamped_pivots"], "reg": info["reg"],
                          "alpha_l2": float(torch.linalg.vector_norm(model.alpha()).item())},

@@ -106,6 +106,14 @@ struct nngp_model {
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
     int iters = 0;
+    // The CG solve for alpha is deferred: nngp_model_solve records where the factor is ready, and the solve runs on its
+    // own stream when alpha is first needed -- inside predict AFTER the covariance work has been enqueued, so that the
+    // HBM-bound CG (float64 GEMV + float32 TRSVs) overlaps the MFMA-bound covariance products.
+    hipStream_t solve_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
+    bool solve_pending = false;
+    int pend_max_iters = 60;
+    double pend_tol = 1e-10;
 
     ~nngp_model() {
         dev_free(x); dev_free(y); dev_free(q); dev_free(kdiag); dev_free(k64); dev_free(a32); dev_free(dinv);
@@ -115,6 +123,9 @@ struct nngp_model {
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
+        if (solve_stream) (void)hipStreamDestroy(solve_stream);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_solved) (void)hipEventDestroy(ev_solved);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
@@ -399,6 +410,14 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         rc = -1;
     }
     if (rc == 0) rc = lookahead_create(&m->la);
+    int prio_least = 0, prio_greatest = 0;  // the solve's many small kernels must not queue behind the covariance GEMMs
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
+    if (rc == 0 && (hipStreamCreateWithPriority(&m->solve_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_solved, hipEventDisableTiming) != hipSuccess)) {
+        set_error("model_create: could not create the solve stream");
+        rc = -1;
+    }
     if (rc == 0 && np >= 4 * kLookAheadNb) {  // the look-ahead factorisation keeps a float16-split copy of one block column
         // ... and keeps the copies of all block columns: the posterior's blocked triangular solves read them again
         m->split.rows_cap = np + 256;
@@ -432,6 +451,7 @@ int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_
     m->n = n;
     m->np = round_up(n, TB);
     m->built = m->factored = m->solved = false;
+    m->solve_pending = false;
     NNGP_HIP_CHECK(hipMemcpyAsync(m->x, x, sizeof(double) * n * m->d, hipMemcpyDeviceToDevice, s));
     NNGP_HIP_CHECK(hipMemcpyAsync(m->y, y, sizeof(double) * n * m->ny, hipMemcpyDeviceToDevice, s));
     NNGP_TRY(launch_row_sqnorm(m->x, n, m->d, m->q, s));
@@ -468,6 +488,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     NNGP_TRY(launch_zero_pad_f64(m->k64, m->ld, m->n, m->np, s));  // float64 GEMMs read the padded matrix
     m->built = true;  // the caller vouches for the remaining rows (all-gather) before factor
     m->factored = m->solved = false;
+    m->solve_pending = false;
     return 0;
 }
 
@@ -478,6 +499,7 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
+    m->solve_pending = false;
     m->split.l_ready = m->split.lt_ready = false;  // set again by the look-ahead factorisation
     return 0;
 }
@@ -561,6 +583,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     m->n = n1;
     m->np = np1;
     m->solved = false;
+    m->solve_pending = false;
     // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
@@ -597,11 +620,12 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     return 0;
 }
 
-int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    NNGP_REQUIRE(m != nullptr && m->factored, "solve: factor first");
-    if (max_iters <= 0) max_iters = 60;
-    if (tol <= 0.0) tol = 1e-10;
+// Runs the deferred CG solve (see nngp_model: solve_stream).  `user`: the stream whose later work needs alpha.
+static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user) {
+    if (!m->solve_pending) return 0;
+    m->solve_pending = false;
+    hipStream_t s = m->solve_stream;
+    NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_ready, 0));
     m->iters = 0;
     m->relres = 0.0;
     for (int c = 0; c < m->ny; ++c) {
@@ -609,12 +633,26 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
         int it = 0;
         double rr = 0.0;
         NNGP_TRY(pcg_solve(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
-                           m->pcg, max_iters, tol, &it, &rr, s));
+                           m->pcg, m->pend_max_iters, m->pend_tol, &it, &rr, s));
         NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
         if (it > m->iters) m->iters = it;
         if (rr > m->relres) m->relres = rr;
     }
+    NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
+    if (order_user) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
+    else NNGP_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->factored, "solve: factor first");
+    m->pend_max_iters = max_iters > 0 ? max_iters : 60;
+    m->pend_tol = tol > 0.0 ? tol : 1e-10;
+    NNGP_HIP_CHECK(hipEventRecord(m->ev_ready, s));  // everything the solve reads has been enqueued on `s`
+    m->solve_pending = true;
     m->solved = true;
+    if (g_debug[7] == 3) return run_pending_solve(m, s, true);  // timing experiment: solve now, in stream order
     return 0;
 }
 
@@ -634,6 +672,7 @@ int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld) {
 
 int nngp_model_info(nngp_model* m, nngp_fit_info* info) {
     NNGP_REQUIRE(m != nullptr && info != nullptr, "model_info: NULL argument");
+    NNGP_TRY(run_pending_solve(m, nullptr, false));
     int32_t cl = 0;
     if (m->factored) NNGP_HIP_CHECK(hipMemcpy(&cl, m->clamped, sizeof(int32_t), hipMemcpyDeviceToHost));
     info->reg = m->reg;
@@ -648,6 +687,7 @@ int nngp_model_info(nngp_model* m, nngp_fit_info* info) {
 
 int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream) {
     NNGP_REQUIRE(m != nullptr && m->solved && alpha_out != nullptr, "model_alpha: solve first");
+    NNGP_TRY(run_pending_solve(m, (hipStream_t)stream, true));
     NNGP_HIP_CHECK(hipMemcpyAsync(alpha_out, m->alpha, sizeof(double) * m->n * m->ny, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
     return 0;
@@ -690,9 +730,9 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
                                         hipMemcpyDeviceToDevice, s));
         ktd = m->ktd64;
     }
-    for (int c = 0; c < m->ny; ++c)
-        NNGP_TRY(launch_gemv_f64(ktd, np, mt, n, m->alpha + c, m->ny, mean + c, m->ny, 0.0, s));
-    if (cov_mode == NNGP_COV_NONE) return 0;
+    // The covariance does not depend on alpha: it is enqueued first, then the deferred CG solve runs on its own stream
+    // (overlapping it), and the mean follows once alpha is there.
+    auto cov_part = [&]() -> int {
     const bool full = (cov_mode == NNGP_COV_FULL);
     if (full) NNGP_TRY(ensure_full_cov_capacity(m, mt));
     NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));  // NNGP K(x_t, x_t)
@@ -775,6 +815,12 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->r64, np, m->z64, np, mp, mp, np, 1.0, 1.0, s));
     NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->covp64, mp, m->z64, np, ktd_n, np, mp, mp, np, -1.0, 1.0, s));
     return launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s);
+    };
+    if (cov_mode != NNGP_COV_NONE) NNGP_TRY(cov_part());
+    NNGP_TRY(run_pending_solve(m, s, true));
+    for (int c = 0; c < m->ny; ++c)
+        NNGP_TRY(launch_gemv_f64(ktd, np, mt, n, m->alpha + c, m->ny, mean + c, m->ny, 0.0, s));
+    return 0;
 }
 
 int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream) {
