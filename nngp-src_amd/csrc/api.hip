@@ -764,6 +764,16 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         //   level L >= 2: L-1 sweeps, then with R = K_td - Z A:  k_i^T A^-1 k_j = sym(z_i . (k_j + r_j)) + O(err^2)
         const int level = m->var_refine;
         const bool second_order = level >= 2;
+        if (!full && second_order) {
+            // diag only: z.(k + r) = 2 z.k - z^T (K + reg I) z, and the quadratic form needs only the lower triangle of
+            // the symmetric K: W = 2 Z strict_lower_blocks(K) + Z diag_blocks(K) -- HALF the float64 product that the
+            // full residual costs (kmode 1 / 2 of the float64 GEMM), then var = K_tt - z.(2 k - W - reg z)
+            NNGP_TRY(refined_solve_rows(m, ktd, mp, level - 1, false, s));
+            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->k64, m->ld, mp, np, np, 2.0, 0.0, s, 1));
+            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, m->r64, np, m->z64, np, m->k64, m->ld, mp, np, np, 1.0, 1.0, s, 2));
+            NNGP_TRY(launch_axpby_mat(m->r64, -1.0, m->z64, -m->reg, np, mp, np, s));
+            return launch_rowdot_f64(m->z64, ktd, 2.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s);
+        }
         NNGP_TRY(refined_solve_rows(m, ktd, mp, second_order ? level - 1 : 1, second_order, s));
         if (!full)
             return launch_rowdot_f64(m->z64, ktd, 1.0, second_order ? m->r64 : nullptr, np, mt, np, m->tt_diag, -1.0,

@@ -132,7 +132,7 @@ int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl,
 // ---- gemm_f64.hip ----
 int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                        const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
-                       hipStream_t s);
+                       hipStream_t s, int kmode = 0);
 
 // ---- solve.hip ----
 int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_t count, hipStream_t s);

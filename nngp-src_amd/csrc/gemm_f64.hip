@@ -26,14 +26,26 @@ __device__ __forceinline__ int lds_off64(int row, int ch) { return row * 128 + (
 
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, const double* Cin, int64_t ldcin,
                                                         const double* A, int64_t lda, const double* B, int64_t ldb,
-                                                        int tiles_m, int nk, double alpha, double beta) {
+                                                        int tiles_m, int nk, double alpha, double beta, int kmode,
+                                                        int tiles_n) {
     __shared__ __attribute__((aligned(16))) double smem[2 * DSTAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // row tile is the fast index: the workgroups that share one 128-row panel of B (the big symmetric kernel matrix)
     // are dispatched together, so the panel is fetched from HBM once and served from L2 / Infinity Cache after that
-    const int bi = blockIdx.x % tiles_m, bj = blockIdx.x / tiles_m;
+    const int bi = blockIdx.x % tiles_m;
+    int bj = blockIdx.x / tiles_m;
+    // kmode (B square and symmetric, quadratic forms z^T B z from its lower triangle only): 1 = only the k blocks
+    // strictly left of the column tile's own 128-block, 2 = only that diagonal block.  The long tiles go first.
+    int t0 = 0, t1 = nk;
+    if (kmode == 1) {
+        bj = tiles_n - 1 - bj;
+        t1 = bj * (DBN / DBK);
+    } else if (kmode == 2) {
+        t0 = bj * (DBN / DBK);
+        t1 = t0 + DBN / DBK;
+    }
     const double* Ab = A + (int64_t)bi * DBM * lda;
     const double* Bb = B + (int64_t)bj * DBN * ldb;
 
@@ -67,11 +79,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
 
     const int r16 = lane & 15, g = lane >> 4;
 
-    load_tile(0);
-    store_tile(0);
+    if (t0 < t1) {
+        load_tile(t0);
+        store_tile(t0 & 1);
+    }
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) load_tile(t + 1);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) load_tile(t + 1);
         const char* sa_ = reinterpret_cast<const char*>(smem + (t & 1) * DSTAGE);
         const char* sb_ = sa_ + DBM * DBK * 8;
 #pragma unroll
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nk) store_tile((t + 1) & 1);
+        if (t + 1 < t1) store_tile((t + 1) & 1);
         __syncthreads();
     }
 
@@ -119,8 +133,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
 
 int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                        const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
-                       hipStream_t s) {
+                       hipStream_t s, int kmode) {
     if (m <= 0 || n <= 0) return 0;
+    NNGP_REQUIRE(kmode == 0 || (kmode >= 1 && kmode <= 2 && n == k), "gemm_nt_f64: the triangular modes need a square B");
     NNGP_REQUIRE(m % DBM == 0 && n % DBN == 0 && k % DBK == 0 && k > 0,
                  "gemm_nt_f64: m, n must be multiples of 128 and k of 16 (m=%lld n=%lld k=%lld)", (long long)m,
                  (long long)n, (long long)k);
@@ -131,7 +146,7 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
     const int64_t tm = m / DBM, tn = n / DBN;
     NNGP_REQUIRE(tm * tn < 2147483647LL, "gemm_nt_f64: grid too large");
     hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
-                       a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta);
+                       a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
