@@ -61,6 +61,7 @@ struct nngp_model {
     int64_t n = 0, np = 0;
     int64_t ld = 0;  // leading dimension of k64 / a32 = np_cap, fixed so that rows can be appended in place
     bool have_train = false, built = false, factored = false, solved = false;
+    bool a32_built = false;  // the kernel build also wrote float32(K) + reg I on the lower tiles of a32 (fused factor input)
 
     // training-side buffers
     double* x = nullptr;      // [n_cap, d]
@@ -484,6 +485,13 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     a.sym = (row_begin == 0 && row_end == m->n) ? 1 : 0;
     a.ld64 = a.ld32 = m->ld;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
+    m->a32_built = false;
+    if (a.sym) {  // whole matrix in one build: the float32 factorisation input falls out of the same epilogue
+        if (m->get == NNGP_GET_NNGP) { a.nngp32 = m->a32; a.diag_add_nngp32 = m->reg; }
+        else { a.ntk32 = m->a32; a.diag_add_ntk32 = m->reg; }
+        a.lower32 = 1;
+        m->a32_built = true;
+    }
     NNGP_TRY(launch_kernel_build(a, m->arch, s));
     NNGP_TRY(launch_zero_pad_f64(m->k64, m->ld, m->n, m->np, s));  // float64 GEMMs read the padded matrix
     m->built = true;  // the caller vouches for the remaining rows (all-gather) before factor
@@ -495,7 +503,11 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
 int nngp_model_factor_begin(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
-    NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, m->n, m->np, m->reg, m->reg + m->trace_mean, s));
+    // a32 = float32(K) + reg I on the lower tiles; if the build already wrote it, only the last (partial + padding)
+    // block row is left
+    NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, m->n, m->np, m->reg, m->reg + m->trace_mean, s,
+                                 m->a32_built ? (m->n / TB) * TB : 0));
+    m->a32_built = false;  // the factorisation overwrites a32
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;

@@ -253,8 +253,17 @@ __global__ __launch_bounds__(256) void k_build(BuildArgs a, ArchDev arch, int64_
         const int64_t gi = i0 + ty + 16 * r, gj = j0 + tx * 4;
         store4(a.nngp64, a.ld64, gi, gj, i_end, j_end, kn[r], vec);
         store4(a.ntk64, a.ld64, gi, gj, i_end, j_end, kt[r], vec);
-        store4(a.nngp32, a.ld32, gi, gj, i_end, j_end, kn[r], vec);
-        store4(a.ntk32, a.ld32, gi, gj, i_end, j_end, kt[r], vec);
+        if (a.nngp32 != nullptr || a.ntk32 != nullptr) {  // float32 copies (factorisation input): regulariser on the diagonal
+            double vn[4], vt[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool diag = a.sym && gi == gj + c;
+                vn[c] = kn[r][c] + (diag ? a.diag_add_nngp32 : 0.0);
+                vt[c] = kt[r][c] + (diag ? a.diag_add_ntk32 : 0.0);
+            }
+            store4(a.nngp32, a.ld32, gi, gj, i_end, j_end, vn, vec);
+            store4(a.ntk32, a.ld32, gi, gj, i_end, j_end, vt, vec);
+        }
     }
 
     // ---- mirror image of an off-diagonal tile (symmetric build): transpose through LDS ----
@@ -279,10 +288,10 @@ __global__ __launch_bounds__(256) void k_build(BuildArgs a, ArchDev arch, int64_
                 const int64_t mi = j0 + ty + 16 * r, mj = i0 + tx * 4;
                 if (which == 0) {
                     store4(a.nngp64, a.ld64, mi, mj, j_end, i_end, v, vec);
-                    store4(a.nngp32, a.ld32, mi, mj, j_end, i_end, v, vec);
+                    if (!a.lower32) store4(a.nngp32, a.ld32, mi, mj, j_end, i_end, v, vec);
                 } else {
                     store4(a.ntk64, a.ld64, mi, mj, j_end, i_end, v, vec);
-                    store4(a.ntk32, a.ld32, mi, mj, j_end, i_end, v, vec);
+                    if (!a.lower32) store4(a.ntk32, a.ld32, mi, mj, j_end, i_end, v, vec);
                 }
             }
         }
