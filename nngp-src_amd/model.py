@@ -112,8 +112,9 @@ class GPModel:
         _lib.check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 
     def set_refine(self, sweeps: int):
-        """Precision level of the posterior covariance: 0 = float32 solve only; 1 = one float64 correction sweep;
-        L >= 2 = L-1 sweeps plus the second-order formula (default 2)."""
+        """Precision level of the posterior covariance: 0 = float32 solve only; 1 = one float64 residual, second-order
+        formula at the float32 solution plus its preconditioned remainder (diag; full covariance: one sweep);
+        L >= 2 = L-1 correction sweeps plus the second-order formula (default 2)."""
         _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 
