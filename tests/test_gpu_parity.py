@@ -521,6 +521,56 @@ def test_full_forest_run_against_c_oracle(golden_dir):
     print("forest full run: cg_iters=%d, q-error median %.4f mean %.3f" % (info["refine_iters"], pa["median"], pa["mean"]))
 
 
+@pytest.mark.parametrize("n,m,d,n_relu,ny", [(4100, 130, 7, 1, 1), (4224, 1, 20, 2, 2), (5003, 1000, 12, 1, 1), (6143, 257, 20, 3, 1)])
+def test_lookahead_sizes_not_multiples_of_the_blocks(n, m, d, n_relu, ny):
+    """N just above the look-ahead threshold and not a multiple of 128 / 1024, M not a multiple of 128: the tail block
+    column, the split copies of the factor and the float16-pipe solves of the posterior against the float64 C oracle."""
+    x, y0 = synth.synthetic_queries(n, d, seed=n)
+    xt, _ = synth.synthetic_queries(m, d, seed=n + 1)
+    y = np.concatenate([y0 * (c + 1) + c for c in range(ny)], axis=1)
+    a = o.make_arch(n_relu)
+    model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3, ny=ny).fit(x, y)
+    info = model.info()
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-9 and info["refine_iters"] <= 10, info
+    mean, var = model.predict(xt, cov="diag")
+    for c in range(ny):
+        ref = c_oracle.fit(x, y[:, c:c + 1], a.w_std, a.b_std)
+        mean_ref, var_ref = c_oracle.predict_nngp(ref, xt, 1)
+        l2, elem = G.mean_gate(mean[:, c:c + 1], mean_ref)
+        assert l2 < 1e-6 and elem < 1e-5, (c, l2, elem, info)
+        if c == 0:
+            np.testing.assert_allclose(var, var_ref, rtol=1e-5, atol=1e-9 * np.abs(var_ref).max())
+    # the float32-only covariance goes through the float16-pipe forward solve too
+    model.set_refine(0)
+    _, var0 = model.predict(xt, cov="diag")
+    assert np.max(np.abs(var0 - var_ref)) <= 2e-2 * np.max(np.abs(var_ref))
+    model.close()
+
+
+def test_ntk_on_the_lookahead_path_and_append():
+    """NTK kernel at a size that takes the look-ahead factorisation and the float16-pipe solves: mean and ensemble
+    covariance against the NumPy oracle, then 300 appended rows against a refit."""
+    n, b, d = 4300, 300, 16
+    x, y = synth.synthetic_queries(n + b, d, seed=11)
+    xt, _ = synth.synthetic_queries(96, d, seed=12)
+    a = o.make_arch(2, 1.1, 0.05)
+    model = GPModel(n + b, d, a.w_std, a.b_std, get="ntk", diag_reg=1e-3).fit(x[:n], y[:n])
+    post = o.Posterior(x[:n], y[:n], a, diag_reg=1e-3)
+    mean, var = model.predict(xt, cov="diag")
+    m_ref, c_ref = post.predict(xt, "ntk", True)
+    assert G.mean_gate(mean, m_ref)[0] < 1e-6
+    np.testing.assert_allclose(var, np.diag(c_ref), rtol=1e-4, atol=1e-8 * np.abs(c_ref).max())
+    model.append(x[n:], y[n:])
+    ref = GPModel(n + b, d, a.w_std, a.b_std, get="ntk", diag_reg=1e-3).fit(x, y)
+    a1, a2 = model.alpha().cpu().numpy(), ref.alpha().cpu().numpy()
+    assert np.linalg.norm(a1 - a2) <= 1e-7 * np.linalg.norm(a2)
+    m1, v1 = model.predict(xt, cov="diag")
+    m2, v2 = ref.predict(xt, cov="diag")
+    assert np.allclose(m1, m2, rtol=1e-8, atol=1e-8 * np.abs(m2).max())
+    np.testing.assert_allclose(v1, v2, rtol=1e-5, atol=1e-8 * np.abs(v2).max())
+    model.close(); ref.close()
+
+
 def test_edge_cases_small_and_degenerate():
     """n = 1, duplicated training rows (K singular without the regulariser), zero test rows, many output columns."""
     a = o.make_arch(1)
