@@ -263,7 +263,7 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     if (g_debug[7] == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
     if (use_split_solves(m, mp)) {
         NNGP_TRY(ensure_lt_split(m, s));
-        return trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
+        return trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt_ready ? m->lt32 : nullptr, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
     }
     return trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s);
 }
@@ -768,7 +768,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         return launch_cov_finish(m->ktt64, mp, m->vvt32, mp, mt, var_or_cov, s);
     }
 
-    NNGP_TRY(ensure_lt(m, s));
+    if (!use_split_solves(m, mp)) NNGP_TRY(ensure_lt(m, s));  // float32 L^T: only the float32 solve path reads it
     NNGP_TRY(ensure_refine_capacity(m, mp));
     if (!is_ntk) {
         // NNGP: cov_ij = K_tt,ij - k_i^T A^-1 k_j with Z ~ K_td A^-1 (float32 solve + float64 correction sweeps).
