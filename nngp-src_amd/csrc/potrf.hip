@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
             // values every lane needs (pivot, column j) travel through a 32-float LDS line read back as
             // broadcasts -- an LDS round trip per column instead of ~500 v_readlane + hazard nops.
             const int i = lane & 31;
-            float a[32], x[32];
+            float a[32], x[32], pinv[32];  // pinv[j] = 1 / L[j][j] (wave-uniform), reused by the inversion
 #pragma unroll
             for (int k = 0; k < 32; ++k) a[k] = Djj[i * LS + k];
 #pragma unroll
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
                 }
                 float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, ~1 ulp: ample for a preconditioner
                 asm volatile("" : "+v"(inv));
+                pinv[j] = inv;
                 const float lij = a[j] * inv;                // L[i][j] for i > j
                 a[j] = (i == j) ? d * inv : lij;
                 const float t = -lij * inv;                  // a[i][k] -= L[i][j] L[k][j] = a[i][k] + t * col[k]
@@ -144,10 +145,14 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
             // inverse: lane c owns column c of X = L^-1;  X[ii][c] = (delta - sum_{k<ii} L[ii][k] X[k][c]) / L[ii][ii]
 #pragma unroll
             for (int ii = 0; ii < 32; ++ii) {
-                float sacc = 0.0f;
+                float s0 = 0.0f, s1 = 0.0f;  // two chains: the sum is latency-, not throughput-bound
 #pragma unroll
-                for (int k = 0; k < ii; ++k) sacc = fmaf(Djj[ii * LS + k], x[k], sacc);  // broadcast LDS reads
-                x[ii] = (((i == ii) ? 1.0f : 0.0f) - sacc) / Djj[ii * LS + ii];
+                for (int k = 0; k + 1 < ii; k += 2) {
+                    s0 = fmaf(Djj[ii * LS + k], x[k], s0);  // broadcast LDS reads
+                    s1 = fmaf(Djj[ii * LS + k + 1], x[k + 1], s1);
+                }
+                if (ii & 1) s0 = fmaf(Djj[ii * LS + ii - 1], x[ii - 1], s0);
+                x[ii] = (((i == ii) ? 1.0f : 0.0f) - (s0 + s1)) * pinv[ii];
             }
             if (lane < 32) {
 #pragma unroll
