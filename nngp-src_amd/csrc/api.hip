@@ -512,7 +512,8 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
     m->solve_pending = false;
-    m->split.l_ready = m->split.lt_ready = false;  // set again by the look-ahead factorisation
+    m->split.l_ready = m->split.lt_ready = false;  // set again by the look-ahead factorisation / factor_end
+    m->split.split_panel = -1;
     return 0;
 }
 
@@ -526,7 +527,7 @@ int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* st
 int nngp_model_factor_update(nngp_model* m, int64_t panel_col0, int64_t panel_width, int64_t col0, int64_t width,
                              void* stream) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor_update: build the kernel rows first");
-    return potrf_update_f32(m->a32, m->np, m->ld, panel_col0, panel_width, col0, width, (hipStream_t)stream);
+    return potrf_update_f32(m->a32, m->np, m->ld, panel_col0, panel_width, col0, width, (hipStream_t)stream, &m->split);
 }
 
 int nngp_model_factor_end(nngp_model* m, void* stream) {
@@ -534,6 +535,16 @@ int nngp_model_factor_end(nngp_model* m, void* stream) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor_end: build the kernel rows first");
     m->tri.bs = triinv_block(m->np);
     NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
+    // the float16-split copy of L by block column, if the factorisation did not leave one behind (recursion at
+    // 4096 <= N, block-column ABI of the distributed factorisation): the posterior's solves use it
+    if (!m->split.l_ready && m->split.planes != nullptr && m->np >= 4 * m->split.k_cap && m->tri.bs == m->split.k_cap &&
+        m->split.rows_cap >= m->np + 256) {
+        const int64_t bs = m->split.k_cap, ldp = 4 * bs;
+        for (int64_t j = 0, o = 0; o + bs < m->np; ++j, o += bs)
+            NNGP_TRY(launch_split_rows(m->a32 + (o + bs) * m->ld + o, m->ld, m->np - o - bs, bs, m->split.scale,
+                                       m->split.planes + j * m->split.col_stride + (o + bs) * ldp, ldp, s));
+        m->split.l_ready = true;
+    }
     m->factored = true;
     m->solved = false;
     m->lt_ready = false;

@@ -103,7 +103,8 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
                                // block column from its measured maximum changed nothing: the float16 pipe keeps
                                // subnormal low planes exact; accuracy is limited by accumulator truncation instead.)
     int* counters = nullptr;   // 8 work counters of the persistent GEMM grid (one per XCD)
-    bool l_ready = false;      // every block column of the current factor has been written (look-ahead factorisation)
+    bool l_ready = false;      // every block column of the current factor has been written
+    int64_t split_panel = -1;  // block-column offset whose split copy was last written by the block-column ABI
     char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)
     bool lt_ready = false;
     char* planes_b = nullptr;  // [mb_cap + 256][k_cap] x 4 bytes: the right-hand-side block of a blocked solve
@@ -125,7 +126,8 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
 constexpr int64_t kLookAheadNb = 1024;  // block-column width of the look-ahead Cholesky
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
                     int64_t w, hipStream_t s);
-int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s);
+int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s,
+                     SplitWork* sw = nullptr);  // sw: run the update on the float16 pipe (split copy of the panel kept in sw)
 int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
                  hipStream_t s);
 

@@ -465,11 +465,33 @@ int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamp
 
 // Apply the finished block column [po, po+pw) to block column [o, o+w), o >= po + pw:
 //   A[o:, o:o+w] -= L[o:, po:po+pw] L[o:o+w, po:po+pw]^T   (lower part of the diagonal block only)
-int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s) {
+int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s,
+                     SplitWork* sw) {
     NNGP_REQUIRE(po >= 0 && pw > 0 && o >= po + pw && w > 0 && o + w <= n && o % TB == 0 && w % TB == 0 && po % TB == 0 &&
                      pw % TB == 0, "potrf_update: bad block columns");
     const float* p = a + o * ld + po;   // panel rows [o, n), columns [po, po+pw)
     float* c = a + o * ld + o;
+    // float16 pipe (same split copies as the single-GPU look-ahead, so the posterior solves find them afterwards): the
+    // panel is split once, when its first update arrives; the leading columns of the first panel stay on the float32
+    // MFMA (accumulator truncation on same-sign sums, see potrf_lookahead_f32)
+    if (sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && pw == sw->k_cap && po % pw == 0 &&
+        sw->rows_cap >= n + 256 && g_debug[2] != 2 && (n - o) * w >= 96 * 256 * 256) {
+        const int64_t ldp = 4 * sw->k_cap;
+        char* col = sw->planes + (po / pw) * sw->col_stride;  // rows at their global index
+        if (sw->split_panel != po) {
+            NNGP_TRY(launch_split_rows(a + (po + pw) * ld + po, ld, n - po - pw, pw, sw->scale, col + (po + pw) * ldp, ldp, s));
+            sw->split_panel = po;
+        }
+        const int64_t lead = (po == 0 && pw > 256) ? 256 : 0;
+        NNGP_TRY(launch_gemm_nt_h3(c, ld, col + o * ldp + lead * 4, col + o * ldp + lead * 4, ldp, n - o, w, pw - lead,
+                                   -1.0f / (sw->scale * sw->scale), 1.0f, true, 0, sw->counters, 0, s));
+        if (lead > 0) {
+            NNGP_TRY(launch_gemm_nt_f32(c, ld, p, ld, p, ld, w, w, lead, -1.0f, 1.0f, true, s));
+            if (n - o - w > 0)
+                NNGP_TRY(launch_gemm_nt_f32(c + w * ld, ld, p + w * ld, ld, p, ld, n - o - w, w, lead, -1.0f, 1.0f, false, s));
+        }
+        return 0;
+    }
     NNGP_TRY(launch_gemm_nt_f32(c, ld, p, ld, p, ld, w, w, pw, -1.0f, 1.0f, true, s));
     const int64_t below = n - o - w;
     if (below > 0)
