@@ -1,15 +1,19 @@
 // "Split-float16" NT GEMM on the gfx950 matrix cores:  C[M,N] = beta*C + alpha * A[M,K] * B[N,K]^T  with float32
-// operands carried as two float16 planes (a*s = hi + lo, hi = fp16(a*s), lo = fp16(a*s - hi): 22 significant bits)
-// and three v_mfma_f32_32x32x16_f16 products per term (hi*hi + hi*lo + lo*hi; lo*lo ~ 2^-22 relative is dropped),
-// accumulated in float32.  The float16 matrix pipe runs 16x the float32 one, so a float32-grade product costs
-// 3/16 of the float32-MFMA time.  Used for the large trailing updates of the blocked Cholesky (SURVEY.md 8a row a3,
-// reference: cho_factor via nt.predict, train.py:171-172): that factor is a preconditioner, its
-// accuracy requirement is "float32 grade", which the split meets (measured: same CG iteration count +-1).
+// operands carried as two float16 planes (a*s = hi + lo, hi = fp16(a*s), lo = fp16(a*s - hi), both rounded to nearest:
+// |a*s - hi - lo| <= 2^-24 |a*s|, and float16 subnormals are exact on this pipe) and three v_mfma_f32_32x32x16_f16
+// products per term (hi*hi + hi*lo + lo*hi; lo*lo ~ 2^-24 relative is dropped), accumulated in float32.  The float16
+// matrix pipe runs 16x the float32 one, so a float32-grade product costs 3/16 of the float32-MFMA time.
+// Used for the large trailing updates of the blocked Cholesky (reference: cho_factor via
+// nt.predict, train.py:171-172) and for the large updates of the posterior's blocked triangular solves (row a4).
+// Accuracy: on random and on real factor panels the result is closer to the float64 product than the float32-MFMA
+// kernel's (2.6e-7 vs 4.0e-7 relative Frobenius).  One caveat: the float16 pipe's accumulator truncates toward zero,
+// a multiplicative bias of -2.6e-8 per 1024 k on same-sign sums and none on mixed signs (scripts/h3_bias.py) -- see
+// potrf_lookahead_f32 for the one place where that matters.
 //
 // Operand format ("split rows", written by k_split_rows): row r is [K/32] blocks of 128 bytes, each block = 32 hi
 // halfs followed by 32 lo halfs of the same 32 k -- so a row's k-block is one 128-byte line, and the panel has the same
 // footprint as its float32 original (4 bytes per element).  s is a power of two chosen by the caller so that
-// max|a*s| <= 2^14 (no float16 overflow; entries down to 2^-16 of the largest keep all 22 bits).
+// max|a*s| < 2^15 (no float16 overflow).
 //
 // Kernel: 512-thread workgroup = 8 waves (2 x 4), tile 256x256, wave sub-tile 128x64 = 4x2 accumulators of 32x32
 // (128 VGPRs), BK = 32 per stage (two k16 MFMA sub-steps), LDS 2 stages x 64 KB filled by global_load_lds_dwordx4,
