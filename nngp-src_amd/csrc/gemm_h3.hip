@@ -304,34 +304,49 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const
         }
         if (group == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
 
-        // epilogue: acc[i][j][r] is element (row, col) with row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
-        const int row_base = bi * HT + wr * 128;
-        const int col_base = bj * HT + wc * 64;
+        // epilogue: acc[i][j][r] is element (row, col) with row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.
+        // The C loads are HBM-latency bound (~2.5 us a round trip): the values of two sub-tiles are requested together, and
+        // the in/out tests use wave-uniform indices so that they are scalar branches (per-lane tests made hipcc wait for
+        // every sub-tile's loads separately).
+        const int row_base = bi * HT + group * 128;  // (group, w4) = (wr, wc) in scalar registers
+        const int col_base = bj * HT + w4 * 64;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            float cold[2][16], ra[16];
+            bool live[2];
+            if (row_alpha != nullptr) {  // per-row operand scales of this 32-row band (both column sub-tiles share them)
+                const int rr = row_base + i * 32 + 4 * fh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ra[r] = (rr < m) ? row_alpha[rr + (r & 3) + 8 * (r >> 2)] : 1.0f;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r0 = row_base + i * 32, c0 = col_base + j * 32;
-                if (r0 >= m || c0 >= n) continue;  // m, n are multiples of 128: a 32x32 sub-tile is inside or outside
-                if (LOWER && (c0 >> 7) > ((r0 + diag_shift) >> 7)) continue;
-                if (ablate & 8) {
+                // m, n are multiples of 128: a 32x32 sub-tile is inside or outside
+                live[j] = r0 < m && c0 < n && !(LOWER && (c0 >> 7) > ((r0 + diag_shift) >> 7)) && !(ablate & 8);
+                if (live[j] && beta != 0.0f) {
+                    const float* p0 = C + (int64_t)(r0 + 4 * fh) * ldc + c0 + frow;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cold[j][r] = p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!live[j]) {
                     asm volatile("" ::"v"(acc[i][j]));
                     continue;
                 }
+                const int r0 = row_base + i * 32, c0 = col_base + j * 32;
                 float* p0 = C + (int64_t)(r0 + 4 * fh) * ldc + c0 + frow;
-                float cold[16];
-                if (beta != 0.0f) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cold[r] = p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc];
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = alpha * acc[i][j][r];
-                    if (row_alpha != nullptr) v *= row_alpha[r0 + 4 * fh + (r & 3) + 8 * (r >> 2)];  // per-row operand scale
-                    if (beta != 0.0f) v = fmaf(beta, cold[r], v);
+                    if (row_alpha != nullptr) v *= ra[r];
+                    if (beta != 0.0f) v = fmaf(beta, cold[j][r], v);
                     p0[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
                 }
             }
+        }
     }
 }
 
