@@ -12,7 +12,20 @@ namespace nngp {
 constexpr int TB = 128;  // Cholesky / GEMM tile edge; all float32 device matrices are padded to it
 
 void set_error(const char* fmt, ...);
-extern int g_debug[8];  // timing experiments (nngp_debug_set); all zero in normal operation
+// Timing-experiment switches (nngp_debug_set / NNGP_DEBUG="key=value,..." in bench.py); all zero in normal operation:
+//   0  bit mask: 1, 2, 4 leaf-kernel ablations (wrong results); 1, 2, 8 split-float16 GEMM ablations (no loads / no MFMA /
+//      no C traffic; wrong results)
+//   1  block-column width of the look-ahead Cholesky (default 1024)
+//   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA
+//   3  1 = slower leaf variant; 3 = kernel build with the float64-MFMA Gram product; 10 + n = first n block columns of the
+//      Cholesky on the float32 MFMA; 20 + c = float32 lead of 128 c columns in the first trailing update (default 256)
+//   4  compute units the persistent split-float16 grid leaves free (default 32 in the Cholesky); panel CUs of the CU-mask
+//      experiment
+//   5  2 = CU-masked streams; 10 + v = tile-block shape of the split-float16 GEMM
+//   6  block size of the inverted diagonal blocks (default 1024)
+//   7  1 = 128-wide recursion in the posterior solves; any non-zero value = float32 solve path; 3 = CG solve in stream
+//      order instead of deferred
+extern int g_debug[8];
 
 #define NNGP_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
