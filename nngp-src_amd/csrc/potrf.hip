@@ -360,6 +360,9 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
                     sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && g_debug[2] != 2;
     if (sw != nullptr) sw->l_ready = sw->lt_ready = false;
+    // (measured and dropped: solving the panel rows in four row chunks on a third stream, each chunk's trailing update
+    // starting as soon as it is solved -- 64.8 vs 59.2 ms: four smaller split-float16 launches lose more in their tails
+    // than the overlap gains)
     // (measured twice and dropped: inverting each diagonal block on the panel stream as it is factored -- neutral, 59.1 vs
     // 58.9 ms, and 58.1 vs 57.9 ms with CUs reserved for the panel stream -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
