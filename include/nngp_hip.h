@@ -140,7 +140,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
 /* Precision level of the posterior covariance (means are float64-accurate at every level).  Z ~ K_td (K + reg I)^-1
  * comes from the float32 factor; each correction sweep costs one [mt, N] x [N, N] float64 MFMA product and one pair
  * of blocked triangular solves and shrinks the error by rho ~ 2e-2 (N = 32768).
- * (max relative error of diag(cov) measured at N = 32768, d = 128, M = 1024; profiles/r1n_var_study.json):
+ * (max relative error of diag(cov) measured at N = 32768, d = 128, M = 1024; profiles/r1o_var_study.json):
  *   0      float32 only, cov = K_tt - V^T V                                                        1e-2
  *   1      diag: z0.(k + r0) + r0.d with r0 = k - A z0, d = M^-1 r0 (one float64 product)           2e-6
  *          full covariance: one sweep, cov = K_tt - sym(Z K_dt)                                     1e-3
