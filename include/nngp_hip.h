@@ -94,9 +94,13 @@ int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, v
  *   set_train : copy X [n, d], Y [n, ny]; row norms, closed-form diagonal, regulariser
  *   build_rows: rows [row_begin, row_end) of the float64 train-train kernel (all columns);
  *               (0, n) takes the symmetric path (lower tiles computed once, mirrored)
- *   factor    : A32 = float32(K) + reg I, blocked lower Cholesky on float32 MFMA, in place
+ *   factor    : A32 = float32(K) + reg I, blocked lower Cholesky in place (panels on the float32 MFMA, the large
+ *               trailing updates as split-float16 MFMA products with float32 accumulation)
  *   solve     : alpha = (K + reg I)^-1 Y by CG on the float64 kernel, preconditioned by the
- *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-10)       */
+ *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-10).
+ *               The call records the request; the CG itself runs on the model's own high-priority stream when alpha
+ *               is first needed -- nngp_model_alpha / _info (which then block for it), or inside nngp_model_predict
+ *               after the covariance work has been enqueued, so that it overlaps it.                          */
 int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_t n, void* stream);
 int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, void* stream);
 int nngp_model_factor(nngp_model* m, void* stream);
