@@ -150,8 +150,18 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  *          full covariance: one sweep, cov = K_tt - sym(Z K_dt)                                     1e-3
  *   2      one sweep + the second-order formula sym(z_i . (k_j + r_j)) (default; the diagonal       4e-7
  *          through the quadratic form z^T A z on the lower triangle of K: 1.5 products)
- *   L > 2  L-1 sweeps + the second-order formula                                     2e-10 at L = 3 */
+ *   L > 2  L-1 sweeps + the second-order formula                                     2e-10 at L = 3
+ * Levels >= 2 are adaptive: the sweeps contract by the spectral radius of I - M^-1 A (M = the float32 factor), which
+ * approaches 1 when cond(K + reg I) * eps32 does (small diag_reg, low-dimensional encodings).  After the fixed sweeps
+ * predict checks two signs of that -- the alpha solve took >= 8 CG iterations (NTK: >= 4), or a row's first-order term
+ * z.r is too large for its second-order error to be small (a loose lower bound: the backstop when the alpha solve says
+ * nothing, e.g. y = 0) -- and then continues the rows by preconditioned
+ * CG (one float64 product + one pair of solves per iteration, each row with its own scalars) until every row's step
+ * lowers e^T A e by less than 1e-8 of its variance, and forms the covariance again.  The check costs one 4-byte
+ * read-back per predict call with a covariance (the call then waits for its own covariance work);
+ * nngp_model_cov_iters returns the iterations the last predict spent there (0: the fixed sweeps were enough). */
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps);
+int nngp_model_cov_iters(nngp_model* m);
 
 /* ---- N2: native query-line encoder (host code; replaces the per-line Python of estimator/encoder.py:59-97,187-250
  * and QuerySampler.py:157-221) --------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_append", "nngp_model_kernel_buffer", "nngp_model_info",
-    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_potrf_f32", "nngp_gemm_nt_f32",
+    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode",
 )
@@ -57,6 +57,10 @@ def load():
         raise NngpError(
             "libnngp_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C nngp-src_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64 / libhsa-runtime64.  Loaded in that order the library's
+    # DT_NEEDED entries resolve to the copies torch already mapped (same SONAME); the other way round the process ends
+    # up with two HSA runtimes and the second one reports "no ROCm-capable device" (seen on the GPU box).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
     archp = ctypes.POINTER(NngpArch)
@@ -86,6 +90,8 @@ def load():
     lib.nngp_encoder_dim.argtypes = [vp]
     lib.nngp_encoder_encode.argtypes = [vp, ctypes.c_char_p, i64, i32, vp, vp, i64, ctypes.POINTER(i64)]
     lib.nngp_model_set_refine.argtypes = [vp, i32]
+    lib.nngp_model_cov_iters.argtypes = [vp]
+    lib.nngp_model_cov_iters.restype = ctypes.c_int
     lib.nngp_model_append.argtypes = [vp, vp, vp, i64, vp]
     lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]

@@ -99,6 +99,9 @@ struct nngp_model {
     double* z64 = nullptr;       // [refine_cap, np_cap]  Z ~ K_td (K + reg I)^-1
     double* r64 = nullptr;       // [refine_cap, np_cap]  residual / product workspace
     double* covp64 = nullptr;    // [fullp, fullp] padded covariance
+    RowsPcg rows{};              // per-row CG that continues the correction sweeps when the float32 factor is a weak preconditioner
+    int64_t rows_pq_cap = 0;     // row capacity of rows.p / rows.q (allocated when a continuation first runs)
+    int cov_iters = 0;           // iterations of the last continuation (0: the fixed sweeps were enough)
     // NTK covariance needs the NNGP kernels as well
     double* kaux64 = nullptr;    // [np_cap, np_cap] NNGP train-train kernel when get == ntk
     bool aux_ready = false;
@@ -130,6 +133,9 @@ struct nngp_model {
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
+        dev_free(rows.p); dev_free(rows.q); dev_free(rows.rho); dev_free(rows.coef); dev_free(rows.tol); dev_free(rows.delta);
+        dev_free(rows.var); dev_free(rows.state); dev_free(rows.live);
+        if (rows.host) (void)hipHostFree(rows.host);
     }
 };
 
@@ -211,6 +217,18 @@ int ensure_refine_capacity(nngp_model* m, int64_t mp) {
         NNGP_TRY(dev_alloc(&m->r64, mp * m->np_cap));
         m->refine_cap = mp;
     }
+    if (mp > m->rows.cap) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        RowsPcg& w = m->rows;
+        dev_free(w.rho); dev_free(w.coef); dev_free(w.tol); dev_free(w.delta); dev_free(w.var); dev_free(w.state);
+        NNGP_TRY(dev_alloc(&w.rho, mp)); NNGP_TRY(dev_alloc(&w.coef, mp)); NNGP_TRY(dev_alloc(&w.tol, mp));
+        NNGP_TRY(dev_alloc(&w.delta, mp)); NNGP_TRY(dev_alloc(&w.var, mp)); NNGP_TRY(dev_alloc(&w.state, mp));
+        if (w.live == nullptr) {
+            NNGP_TRY(dev_alloc(&w.live, 2));
+            NNGP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&w.host), 2 * sizeof(int32_t), hipHostMallocDefault));
+        }
+        w.cap = mp;
+    }
     return 0;
 }
 
@@ -282,6 +300,40 @@ int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps,
         NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
         NNGP_TRY(apply_inverse_f32(m, mp, s));
         NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, true, s));
+    }
+    return 0;
+}
+
+// Continues the correction of z64 (rows of rhs (K + reg I)^-1) by preconditioned CG, every row with its own scalars,
+// until each row's step no longer lowers e^T A e by more than rows.tol[row] (twice in a row) or max_iters is reached.
+// In: z64 and its residual r64 = rhs - z64 (K + reg I); out: both updated.  The stationary sweeps contract by the
+// spectral radius of I - M^-1 A, which approaches 1 when cond(K + reg I) * eps32 does (small diag_reg, low-dimensional
+// encodings: seen at cond 2.6e7, where four sweeps left 4e-2 in the variance); CG on the same operator needs ~the
+// iteration count of the alpha solve.  One host read-back per iteration (the count of rows still iterating).
+int rows_pcg_continue(nngp_model* m, int64_t mp, int max_iters, hipStream_t s) {
+    const int64_t np = m->np;
+    RowsPcg& w = m->rows;
+    if (mp > m->rows_pq_cap) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(w.p); dev_free(w.q);
+        w.p = w.q = nullptr;
+        NNGP_TRY(dev_alloc(&w.p, mp * m->np_cap));
+        NNGP_TRY(dev_alloc(&w.q, mp * m->np_cap));
+        m->rows_pq_cap = mp;
+    }
+    m->cov_iters = 0;
+    for (int it = 0; it < max_iters; ++it) {
+        NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
+        NNGP_TRY(apply_inverse_f32(m, mp, s));
+        NNGP_TRY(launch_rows_rho(m->r64, m->b32, np, mp, np, it == 0, w, s));
+        NNGP_TRY(launch_rows_update_p(w.p, m->b32, np, mp, np, w, s));
+        NNGP_TRY(launch_gemm_nt_f64(w.q, np, w.p, np, w.p, np, m->k64, m->ld, mp, np, np, 1.0, m->reg, s));
+        NNGP_TRY(launch_rows_alpha(w.p, w.q, np, mp, np, w, s));
+        NNGP_TRY(launch_rows_axpy2(m->z64, m->r64, w.p, w.q, np, mp, np, w, s));
+        NNGP_HIP_CHECK(hipMemcpyAsync(w.host, w.live, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        NNGP_HIP_CHECK(hipStreamSynchronize(s));
+        m->cov_iters = it + 1;
+        if (w.host[0] == 0) break;
     }
     return 0;
 }
@@ -716,6 +768,11 @@ int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream) {
     return 0;
 }
 
+int nngp_model_cov_iters(nngp_model* m) {
+    NNGP_REQUIRE(m != nullptr, "cov_iters: NULL model");
+    return m->cov_iters;
+}
+
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps) {
     NNGP_REQUIRE(m != nullptr && sweeps >= 0 && sweeps <= 8, "set_refine: level must be in [0, 8]");
     m->var_refine = sweeps;
@@ -755,8 +812,25 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     }
     // The covariance does not depend on alpha: it is enqueued first, then the deferred CG solve runs on its own stream
     // (overlapping it), and the mean follows once alpha is there.
-    auto cov_part = [&]() -> int {
+    // Levels >= 2 check afterwards whether the fixed number of correction sweeps was enough (cov_adaptive below):
+    // 0 nothing to check, 1 NNGP diag, 2 NNGP full, 3 NTK.
+    int check_kind = 0;
     const bool full = (cov_mode == NNGP_COV_FULL);
+    const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
+    auto ntk_finish = [&]() -> int {    // from z64 = Theta_td (Theta_dd + reg I)^-1; K_tt already in ktt64 (full)
+        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd
+        if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
+            return launch_rowdot_f64(m->z64, ntk_cross, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);
+        NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ntk_cross, -1.0, np, mp, np, s));  // G = W - K_td
+        NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->r64, np, m->z64, np, mp, mp, np, 1.0, 1.0, s));
+        NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->covp64, mp, m->z64, np, ntk_cross, np, mp, mp, np, -1.0, 1.0, s));
+        return launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s);
+    };
+    // Row flag: a LOWER bound of the remaining relative variance error above this value (debug key 6 = e >= 2: 10^-e).
+    // The bound is loose -- measured 1e-10 where the error is 4e-7 (N = 32768, scripts/flag_study.py) -- so it is only the
+    // backstop for fits whose alpha solve says nothing about the conditioning (e.g. y = 0 converges at once).
+    const double kFlagThr = g_debug[6] >= 2 ? pow(10.0, -(double)g_debug[6]) : 1e-8;
+    auto cov_part = [&]() -> int {
     if (full) NNGP_TRY(ensure_full_cov_capacity(m, mt));
     NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));  // NNGP K(x_t, x_t)
     auto build_ktt = [&]() -> int {  // NNGP K_tt [mt, mt] into ktt64 (ld = mp)
@@ -810,7 +884,12 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->k64, m->ld, mp, np, np, 2.0, 0.0, s, 1));
             NNGP_TRY(launch_gemm_nt_f64(m->r64, np, m->r64, np, m->z64, np, m->k64, m->ld, mp, np, np, 1.0, 1.0, s, 2));
             NNGP_TRY(launch_axpby_mat(m->r64, -1.0, m->z64, -m->reg, np, mp, np, s));
-            return launch_rowdot_f64(m->z64, ktd, 2.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s);
+            NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 2.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
+            // delta = z.k - z^T A z: the first-order term that the formula above cancels (cov_adaptive reads the flags)
+            NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s));
+            check_kind = 1;
+            return launch_rows_prepare(m->rows.delta, m->tt_diag, var_or_cov, nullptr, 0, kFlagThr, mt, m->rows.tol,
+                                       m->rows.live + 1, s);
         }
         NNGP_TRY(refined_solve_rows(m, ktd, mp, second_order ? level - 1 : 1, second_order, s));
         if (!full)
@@ -818,6 +897,11 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
                                      var_or_cov, s);
         const double* g = ktd;
         if (second_order) {
+            NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, m->rows.var, s));
+            NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s));
+            NNGP_TRY(launch_rows_prepare(m->rows.delta, m->tt_diag, m->rows.var, nullptr, 0, kFlagThr, mt, m->rows.tol,
+                                         m->rows.live + 1, s));
+            check_kind = 2;
             NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, 1.0, np, mp, np, s));  // G = K_td + R
             g = m->r64;
         }
@@ -855,17 +939,52 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         ktd_n = m->ktd_aux;
     }
     NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine < 2 ? 2 : m->var_refine, false, s));  // no error cancellation: >= 2 sweeps
-    NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd
-    if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
-        return launch_rowdot_f64(m->z64, ktd_n, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);
-    NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd_n, -1.0, np, mp, np, s));  // G = W - K_td
-    NNGP_TRY(build_ktt());
-    NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->r64, np, m->z64, np, mp, mp, np, 1.0, 1.0, s));
-    NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->covp64, mp, m->z64, np, ktd_n, np, mp, mp, np, -1.0, 1.0, s));
-    return launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s);
+    ntk_cross = ktd_n;
+    if (full) NNGP_TRY(build_ktt());
+    if (m->var_refine >= 2) check_kind = 3;
+    return ntk_finish();
     };
     if (cov_mode != NNGP_COV_NONE) NNGP_TRY(cov_part());
     NNGP_TRY(run_pending_solve(m, s, true));
+    // Were the fixed sweeps enough?  Two signs that the float32 factor is a weak preconditioner: the alpha solve needed
+    // many CG iterations, or a row's first-order term is too large for its second-order error to be small (k_rows_prepare).
+    // Then the rows go on by preconditioned CG until each has converged, and the covariance is formed again.
+    // (debug key 6 = 1: fixed sweeps only.)
+    m->cov_iters = 0;
+    if (check_kind != 0 && g_debug[6] != 1) {
+        // Iterations of the alpha solve against the variance error of the fixed sweeps, 72 random fits of
+        // tests/test_gpu_parity.py (N <= 5200): <= 5: <= 1e-7, 6: <= 1e-5, 7: <= 5e-5, >= 9: up to 8e-2; the bench sizes
+        // need 5 (N = 32768) and 6 (N = 65536).  NTK covariance has no second-order formula: stricter.
+        bool weak = m->iters >= (is_ntk ? 4 : 8);
+        if (!weak && check_kind != 3) {
+            NNGP_HIP_CHECK(hipMemcpyAsync(m->rows.host + 1, m->rows.live + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            NNGP_HIP_CHECK(hipStreamSynchronize(s));
+            weak = m->rows.host[1] > 0;
+        }
+        if (weak) {
+            if (check_kind == 2) {
+                NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, -1.0, np, mp, np, s));  // back from G = K_td + R to R
+            } else {
+                NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
+                NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+            }
+            if (check_kind == 3) {  // tolerance relative to the energy z.k of each row
+                NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, nullptr, np, mt, np, nullptr, 1.0, m->rows.delta, s));
+                NNGP_TRY(launch_rows_prepare(nullptr, nullptr, nullptr, m->rows.delta, 1, 0.0, mt, m->rows.tol,
+                                             m->rows.live + 1, s));
+            }
+            NNGP_TRY(rows_pcg_continue(m, mp, 80, s));
+            if (check_kind == 3) {
+                NNGP_TRY(ntk_finish());
+            } else if (!full) {
+                NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
+            } else {
+                NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, 1.0, np, mp, np, s));  // G = K_td + R
+                NNGP_TRY(launch_gemm_nt_f64(m->covp64, mp, m->ktt64, mp, m->z64, np, m->r64, np, mp, mp, np, -1.0, 1.0, s));
+                NNGP_TRY(launch_copy_mat_f64(m->covp64, mp, var_or_cov, mt, s));
+            }
+        }
+    }
     for (int c = 0; c < m->ny; ++c)
         NNGP_TRY(launch_gemv_f64(ktd, np, mt, n, m->alpha + c, m->ny, mean + c, m->ny, 0.0, s));
     return 0;

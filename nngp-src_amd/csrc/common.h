@@ -203,6 +203,29 @@ int launch_axpby_mat(double* r, double a, const double* k, double b, int64_t ld,
 int launch_rowdot_f64(const double* z, const double* k, double kscale, const double* r, int64_t ld, int64_t rows,
                       int64_t cols, const double* base, double sign, double* out, hipStream_t s);
 int launch_copy_mat_f64(const double* src, int64_t lds, double* dst, int64_t m, hipStream_t s);
+// per-row preconditioned CG over [rows, cols] blocks (api.hip: rows_pcg_continue)
+struct RowsPcg {
+    int64_t cap = 0;          // padded row capacity
+    double* p = nullptr;      // [cap, np_cap] search directions
+    double* q = nullptr;      // [cap, np_cap] (K + reg I) p
+    double* rho = nullptr;    // [cap] r . M^-1 r
+    double* coef = nullptr;   // [cap] beta, then alpha of the current step
+    double* tol = nullptr;    // [cap] stopping threshold on the per-step decrease of e^T A e
+    double* delta = nullptr;  // [cap] first-order term z . r of the fixed sweeps
+    double* var = nullptr;    // [cap] variance estimate of the fixed sweeps (full-covariance mode)
+    int32_t* state = nullptr; // [cap] >= 0: consecutive small steps; -1: finished
+    int32_t* live = nullptr;  // [2] rows still iterating; rows flagged by k_rows_prepare
+    int32_t* host = nullptr;  // pinned [2]
+};
+int launch_rows_prepare(const double* delta, const double* ktt, const double* var, const double* q, int mode, double thr,
+                        int64_t rows, double* tol, int32_t* flagged, hipStream_t s);
+int launch_rows_rho(const double* r, const float* s32, int64_t ld, int64_t rows, int64_t cols, bool first, RowsPcg& w,
+                    hipStream_t s);
+int launch_rows_update_p(double* p, const float* s32, int64_t ld, int64_t rows, int64_t cols, RowsPcg& w, hipStream_t s);
+int launch_rows_alpha(const double* p, const double* q, int64_t ld, int64_t rows, int64_t cols, RowsPcg& w, hipStream_t s);
+int launch_rows_axpy2(double* z, double* r, const double* p, const double* q, int64_t ld, int64_t rows, int64_t cols,
+                      RowsPcg& w, hipStream_t s);
+
 int launch_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t n, hipStream_t s);
 int launch_strided_copy_f64(const double* src, int64_t incs, double* dst, int64_t incd, int64_t n, hipStream_t s);
 

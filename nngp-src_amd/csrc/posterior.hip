@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_axpby_mat(double* __restrict__ r, doubl
     r[row * ld + c] = fma(b, k[row * ld + c], a * r[row * ld + c]);
 }
 
-// out[i] = base[i] + sign * sum_j z[i][j] * (kscale * k[i][j] + r[i][j])   (k or r may be NULL)
+// out[i] = base[i] + sign * sum_j z[i][j] * (kscale * k[i][j] + r[i][j])   (k, r or base may be NULL)
 __global__ __launch_bounds__(256) void k_rowdot_f64(const double* __restrict__ z, const double* __restrict__ k,
                                                     double kscale, const double* __restrict__ r, int64_t ld,
                                                     int64_t cols, const double* __restrict__ base, double sign,
@@ -133,7 +133,110 @@ __global__ __launch_bounds__(256) void k_rowdot_f64(const double* __restrict__ z
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[row] = base[row] + sign * (red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) out[row] = (base ? base[row] : 0.0) + sign * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- per-row preconditioned CG on [rows, cols] blocks: every row is an independent right-hand side of the same SPD ----
+// system (rows_pcg_continue in api.hip drives these; RowsPcg in common.h holds the per-row scalars).
+__device__ __forceinline__ double block_sum_256(double s, double* red) {
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// Decides which rows need more than the fixed correction sweeps and sets their stopping tolerance.
+//   mode 0 (NNGP): delta = z.r is the first-order term the second-order variance formula cancels; by Cauchy-Schwarz
+//     the remaining error e^T A e is at least delta^2 / (k^T A^-1 k), so delta^2 > thr * q * var flags the row.
+//     tol = the decrease of e^T A e per CG step below which the row stops: 1e-8 of the variance estimate.
+//   mode 1 (NTK, no second-order formula): every row runs; tol relative to the energy q = z.k.
+__global__ void k_rows_prepare(const double* __restrict__ delta, const double* __restrict__ ktt, const double* __restrict__ var,
+                               const double* __restrict__ q, int mode, double thr, int64_t rows, double* __restrict__ tol,
+                               int32_t* __restrict__ flagged) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    if (mode == 1) {
+        tol[i] = 1e-13 * fabs(q[i]);
+        return;
+    }
+    const double v = var[i], prior = ktt[i], e = prior - v;
+    tol[i] = fmax(1e-8 * fmax(v, 0.0), 1e-15 * prior);
+    const bool bad = !(v > 0.0) || !(delta[i] * delta[i] <= thr * fmax(e, 0.0) * v);
+    if (bad) atomicAdd(flagged, 1);
+}
+
+// rho_new = r . s (s = M^-1 r in float32); beta = rho_new / rho_old; a row whose rho is not positive is finished
+__global__ __launch_bounds__(256) void k_rows_rho(const double* __restrict__ r, const float* __restrict__ s32, int64_t ld,
+                                                  int64_t cols, int first, double* __restrict__ rho, double* __restrict__ coef,
+                                                  int32_t* __restrict__ state) {
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < cols; j += 256) acc = fma(r[row * ld + j], (double)s32[row * ld + j], acc);
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) {
+        if (first) state[row] = 0;
+        double beta = 0.0;
+        if (state[row] >= 0) {
+            if (!(acc > 0.0) || !isfinite(acc)) state[row] = -1;
+            else if (!first && rho[row] > 0.0) beta = acc / rho[row];
+        }
+        rho[row] = acc;
+        coef[row] = beta;
+    }
+}
+
+// p = s + beta p   (finished rows: p = 0)
+__global__ __launch_bounds__(256) void k_rows_update_p(double* __restrict__ p, const float* __restrict__ s32, int64_t ld,
+                                                       int64_t cols, const double* __restrict__ coef,
+                                                       const int32_t* __restrict__ state) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const bool live = state[row] >= 0;
+    p[row * ld + c] = live ? fma(coef[row], p[row * ld + c], (double)s32[row * ld + c]) : 0.0;
+}
+
+// alpha = rho / (p . q); gain = alpha rho = decrease of e^T A e in this step.  Two consecutive gains below tol finish
+// the row (after this update).  `live` counts the rows that go on.
+__global__ __launch_bounds__(256) void k_rows_alpha(const double* __restrict__ p, const double* __restrict__ q, int64_t ld,
+                                                    int64_t cols, const double* __restrict__ rho, const double* __restrict__ tol,
+                                                    double* __restrict__ coef, int32_t* __restrict__ state,
+                                                    int32_t* __restrict__ live) {
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < cols; j += 256) acc = fma(p[row * ld + j], q[row * ld + j], acc);
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) {
+        double alpha = 0.0;
+        int32_t st = state[row];
+        if (st >= 0) {
+            if (acc > 0.0 && isfinite(acc)) {
+                alpha = rho[row] / acc;
+                st = (alpha * rho[row] <= tol[row]) ? st + 1 : 0;
+                if (st >= 2) st = -1;
+            } else {
+                st = -1;
+            }
+            state[row] = st;
+            if (st >= 0) atomicAdd(live, 1);
+        }
+        coef[row] = alpha;
+    }
+}
+
+// z += alpha p;  r -= alpha q
+__global__ __launch_bounds__(256) void k_rows_axpy2(double* __restrict__ z, double* __restrict__ r, const double* __restrict__ p,
+                                                    const double* __restrict__ q, int64_t ld, int64_t cols,
+                                                    const double* __restrict__ coef) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const double a = coef[row];
+    if (a == 0.0) return;
+    z[row * ld + c] = fma(a, p[row * ld + c], z[row * ld + c]);
+    r[row * ld + c] = fma(-a, q[row * ld + c], r[row * ld + c]);
 }
 
 // dst[m, m] (dense) = (src + src^T) / 2 of src[m, m] (leading dimension lds).  The symmetric part is where the
@@ -274,6 +377,46 @@ int launch_rowdot_f64(const double* z, const double* k, double kscale, const dou
                       int64_t cols, const double* base, double sign, double* out, hipStream_t s) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_rowdot_f64, dim3((unsigned)rows), dim3(256), 0, s, z, k, kscale, r, ld, cols, base, sign, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_prepare(const double* delta, const double* ktt, const double* var, const double* q, int mode, double thr,
+                        int64_t rows, double* tol, int32_t* flagged, hipStream_t s) {
+    if (rows <= 0) return 0;
+    NNGP_HIP_CHECK(hipMemsetAsync(flagged, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_rows_prepare, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, delta, ktt, var, q, mode, thr, rows,
+                       tol, flagged);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_rho(const double* r, const float* s32, int64_t ld, int64_t rows, int64_t cols, bool first, RowsPcg& w,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_rho, dim3((unsigned)rows), dim3(256), 0, s, r, s32, ld, cols, first ? 1 : 0, w.rho, w.coef, w.state);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_update_p(double* p, const float* s32, int64_t ld, int64_t rows, int64_t cols, RowsPcg& w, hipStream_t s) {
+    NNGP_REQUIRE(rows <= 65535, "rows_pcg: at most 65535 rows per call");
+    hipLaunchKernelGGL(k_rows_update_p, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, s, p, s32, ld, cols,
+                       w.coef, w.state);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_alpha(const double* p, const double* q, int64_t ld, int64_t rows, int64_t cols, RowsPcg& w, hipStream_t s) {
+    NNGP_HIP_CHECK(hipMemsetAsync(w.live, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_rows_alpha, dim3((unsigned)rows), dim3(256), 0, s, p, q, ld, cols, w.rho, w.tol, w.coef, w.state, w.live);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_axpy2(double* z, double* r, const double* p, const double* q, int64_t ld, int64_t rows, int64_t cols,
+                      RowsPcg& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_axpy2, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, s, z, r, p, q, ld, cols,
+                       w.coef);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -118,6 +118,11 @@ class GPModel:
         _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 
+    def cov_iters(self) -> int:
+        """CG iterations the last predict spent continuing the covariance solve beyond the fixed sweeps (levels >= 2 do
+        that when the float32 factor is a weak preconditioner; 0 = the fixed sweeps were enough)."""
+        return int(self.lib.nngp_model_cov_iters(self.handle))
+
     def fit(self, x, y):
         self.set_train(x, y)
         self.build_rows(0, self.n)

@@ -5,6 +5,7 @@ north-star gate of 1e-4 relative (we assert 1e-6: CG on the float64 kernel conve
 answer); variances 1e-3 relative (float32 triangular solve); float32 MFMA GEMM is checked bit-exactly
 on integer data and to float32 rounding on random data.
 """
+import json
 import os
 
 import numpy as np
@@ -608,3 +609,59 @@ def test_edge_cases_small_and_degenerate():
         md.predict(np.zeros((3, 19)))
     with pytest.raises(ValueError):
         GPModel(10, 4, a.w_std, a.b_std).fit(np.zeros((11, 4)), np.zeros((11, 1)))
+
+
+# ---------------------------------------------------------------------------- seeded random sweep over the whole operator surface
+def _sweep_case(seed):
+    r = np.random.default_rng(1000 + seed)
+    get = "ntk" if seed % 3 == 2 else "nngp"
+    n = int(r.integers(40, 1600 if get == "ntk" else 5200))
+    return dict(seed=seed, get=get, n=n, m=int(r.integers(1, 400)), d=int(r.choice([2, 3, 7, 20, 64, 128, 200, 256])),
+                n_relu=int(r.integers(1, 5)), w=float(r.uniform(0.6, 1.8)), b=float(r.choice([0.0, 0.05, 0.3])),
+                diag_reg=float(r.choice([1e-4, 1e-3, 1e-2])), absolute=bool(r.integers(0, 4) == 0), join=bool(r.integers(0, 3) == 0))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNGP_SWEEP_CASES", "12"))))  # more cases: set the variable
+def test_random_sweep_against_the_float64_oracle(seed):
+    """Random architecture (depth, W_std, b_std), regulariser (size, relative/absolute), sizes off every block grid and
+    both encodings: float64 kernel, alpha, mean and variance of the HIP path against the float64 oracle.  One line per
+    case is appended to gpurun_out/parity_sweep.jsonl (summary committed as profiles/*_parity_sweep.jsonl)."""
+    c = _sweep_case(seed)
+    if c["absolute"]:  # diag_reg_absolute_scale: reg is not scaled by trace/N, so give it the kernel's own scale (~|x|^2/d)
+        c["diag_reg"] *= 1e5
+    x, y = synth.synthetic_queries(c["n"], c["d"], seed=seed, join_block=c["join"] and c["d"] >= 8)
+    xt, _ = synth.synthetic_queries(c["m"], c["d"], seed=seed + 100, join_block=c["join"] and c["d"] >= 8)
+    a = o.make_arch(c["n_relu"], c["w"], c["b"])
+    model = GPModel(c["n"], c["d"], a.w_std, a.b_std, get=c["get"], diag_reg=c["diag_reg"],
+                    diag_reg_absolute_scale=c["absolute"]).fit(x, y)
+    info = model.info()
+    mean, var = model.predict(xt, cov="diag")
+    cov_iters = model.cov_iters()
+    _, cov = model.predict(xt[:64], cov="full")
+    assert np.abs(np.diag(cov) - var[:64]).max() <= 1e-5 * np.abs(var[:64]).max()
+    if c["get"] == "nngp":
+        ref = c_oracle.fit(x, y, a.w_std, a.b_std, diag_reg=c["diag_reg"], absolute=c["absolute"])
+        mean_ref, var_ref = c_oracle.predict_nngp(ref, xt, 1)
+        alpha_ref, reg_ref = ref["alpha"], ref["reg"]
+    else:
+        post = o.Posterior(x, y, a, diag_reg=c["diag_reg"], diag_reg_absolute_scale=c["absolute"])
+        mean_ref, cov_ref = post.predict(xt, "ntk", True)
+        var_ref, alpha_ref = np.diag(cov_ref), post._factor("ntk")[2]
+        reg_ref = c["diag_reg"] * (1.0 if c["absolute"] else np.trace(post._factor("ntk")[0]) / c["n"])
+    l2, elem = G.mean_gate(mean, mean_ref)
+    row = dict(c, reg_rel=abs(info["reg"] - reg_ref) / reg_ref, cg_iters=info["refine_iters"], cov_iters=cov_iters,
+               clamped=info["clamped_pivots"],
+               alpha_rel_l2=G.rel_l2(model.alpha().cpu().numpy(), alpha_ref), mean_rel_l2=l2, mean_elem=elem,
+               var_max_rel=float(np.max(np.abs(var - var_ref.ravel()) / np.maximum(np.abs(var_ref.ravel()), 1e-9 * np.abs(var_ref).max()))))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_sweep.jsonl", "a") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
+    model.close()
+    assert row["clamped"] == 0 and row["reg_rel"] < 1e-8, row
+    # small regularisers (1e-4 relative, or absolute on a large-trace kernel) raise cond(K + reg I): alpha itself is
+    # then determined to ~cond * eps64 only, the mean stays at the gate
+    assert row["mean_rel_l2"] < 1e-6 and row["mean_elem"] < 1e-5, row
+    assert row["var_max_rel"] < 1e-4, row
