@@ -661,7 +661,41 @@ def test_random_sweep_against_the_float64_oracle(seed):
         pass
     model.close()
     assert row["clamped"] == 0 and row["reg_rel"] < 1e-8, row
+    if c["get"] == "nngp" and row["cg_iters"] >= 8:  # weak preconditioner: the rows must have gone on by CG
+        assert cov_iters > 0 and row["var_max_rel"] < 1e-6, row
     # small regularisers (1e-4 relative, or absolute on a large-trace kernel) raise cond(K + reg I): alpha itself is
     # then determined to ~cond * eps64 only, the mean stays at the gate
     assert row["mean_rel_l2"] < 1e-6 and row["mean_elem"] < 1e-5, row
     assert row["var_max_rel"] < 1e-4, row
+
+
+def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
+    """The ill-conditioned fit of the sweep (seed 6: d=3, 4-layer, diag_reg=1e-4, cond 2.6e7) with y = 0: the alpha solve
+    converges at once, so only the row flag can tell that the fixed sweeps were not enough.  The covariance does not
+    depend on y: it must equal the one of the fit with the real targets (which continues by CG because of its 13
+    alpha iterations), at the diag and the full level."""
+    c = _sweep_case(6)
+    x, y = synth.synthetic_queries(c["n"], c["d"], seed=6)
+    xt, _ = synth.synthetic_queries(c["m"], c["d"], seed=106)
+    a = o.make_arch(c["n_relu"], c["w"], c["b"])
+    ref_model = GPModel(c["n"], c["d"], a.w_std, a.b_std, diag_reg=c["diag_reg"]).fit(x, y)
+    _, var_ref = ref_model.predict(xt, cov="diag")
+    assert ref_model.info()["refine_iters"] >= 8 and ref_model.cov_iters() > 0
+    model = GPModel(c["n"], c["d"], a.w_std, a.b_std, diag_reg=c["diag_reg"]).fit(x, np.zeros_like(y))
+    assert model.info()["refine_iters"] <= 1
+    mean, var = model.predict(xt, cov="diag")
+    assert model.cov_iters() > 0
+    assert np.all(mean == 0.0)
+    np.testing.assert_allclose(var, var_ref, rtol=1e-6)
+    _, cov = model.predict(xt, cov="full")
+    assert model.cov_iters() > 0
+    np.testing.assert_allclose(np.diag(cov), var_ref, rtol=1e-6)
+    # fixed sweeps only (what levels >= 2 did before): far off
+    from nngp_src_amd import _lib
+    _lib.load().nngp_debug_set(6, 1)
+    try:
+        _, var_fixed = model.predict(xt, cov="diag")
+    finally:
+        _lib.load().nngp_debug_set(6, 0)
+    assert model.cov_iters() == 0 and np.max(np.abs(var_fixed - var_ref) / var_ref) > 1e-3
+    model.close(); ref_model.close()
