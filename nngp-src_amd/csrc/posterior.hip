@@ -399,9 +399,11 @@ int launch_rows_rho(const double* r, const float* s32, int64_t ld, int64_t rows,
 }
 
 int launch_rows_update_p(double* p, const float* s32, int64_t ld, int64_t rows, int64_t cols, RowsPcg& w, hipStream_t s) {
-    NNGP_REQUIRE(rows <= 65535, "rows_pcg: at most 65535 rows per call");
-    hipLaunchKernelGGL(k_rows_update_p, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, s, p, s32, ld, cols,
-                       w.coef, w.state);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = (rows - r0 < 65535) ? rows - r0 : 65535;
+        hipLaunchKernelGGL(k_rows_update_p, dim3((unsigned)((cols + 255) / 256), (unsigned)nr), dim3(256), 0, s, p + r0 * ld,
+                           s32 + r0 * ld, ld, cols, w.coef + r0, w.state + r0);
+    }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -415,8 +417,11 @@ int launch_rows_alpha(const double* p, const double* q, int64_t ld, int64_t rows
 
 int launch_rows_axpy2(double* z, double* r, const double* p, const double* q, int64_t ld, int64_t rows, int64_t cols,
                       RowsPcg& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_rows_axpy2, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, s, z, r, p, q, ld, cols,
-                       w.coef);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = (rows - r0 < 65535) ? rows - r0 : 65535;
+        hipLaunchKernelGGL(k_rows_axpy2, dim3((unsigned)((cols + 255) / 256), (unsigned)nr), dim3(256), 0, s, z + r0 * ld,
+                           r + r0 * ld, p + r0 * ld, q + r0 * ld, ld, cols, w.coef + r0);
+    }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -699,3 +699,25 @@ def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
         _lib.load().nngp_debug_set(6, 0)
     assert model.cov_iters() == 0 and np.max(np.abs(var_fixed - var_ref) / var_ref) > 1e-3
     model.close(); ref_model.close()
+
+
+@pytest.mark.parametrize("log2_scale", [-12, 9])
+def test_power_of_two_input_scaling_is_exact(log2_scale):
+    """With b_std = 0 the ReLU kernel is homogeneous of degree 2 in x, and the relative regulariser scales with it, so
+    scaling every query by 2^k leaves the posterior mean unchanged and scales the variance by 4^k.  Powers of two commute
+    with every rounding on the path (float64 build, float32 factor, the power-of-two scale of the float16 split, CG), so
+    the results must agree to the last bit -- a size-independent check of the scale handling of the float16-pipe Cholesky
+    (N = 4500 takes the look-ahead path)."""
+    n, m, d = 4500, 200, 24
+    x, y = synth.synthetic_queries(n, d, seed=3)
+    xt, _ = synth.synthetic_queries(m, d, seed=4)
+    a = o.make_arch(2)
+    base = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
+    mean0, var0 = base.predict(xt, cov="diag")
+    c = 2.0 ** log2_scale
+    scaled = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x * c, y)
+    mean1, var1 = scaled.predict(xt * c, cov="diag")
+    assert scaled.info()["refine_iters"] == base.info()["refine_iters"]
+    assert np.array_equal(mean1, mean0)
+    assert np.array_equal(var1, var0 * c * c)
+    base.close(); scaled.close()
