@@ -698,6 +698,13 @@ def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
     finally:
         _lib.load().nngp_debug_set(6, 0)
     assert model.cov_iters() == 0 and np.max(np.abs(var_fixed - var_ref) / var_ref) > 1e-3
+    # x_test=None (estimator.py:37-40): variances at the training rows, against the float64 C oracle
+    mean_tr, var_tr = ref_model.predict(None, cov="diag")
+    assert ref_model.cov_iters() > 0
+    orc = c_oracle.fit(x, y, a.w_std, a.b_std, diag_reg=c["diag_reg"])
+    mtr_ref, vtr_ref = c_oracle.predict_nngp(orc, x, 1)
+    assert G.mean_gate(mean_tr, mtr_ref)[0] < 1e-6
+    np.testing.assert_allclose(var_tr, vtr_ref.ravel(), rtol=1e-5)
     model.close(); ref_model.close()
 
 
