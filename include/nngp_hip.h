@@ -95,15 +95,22 @@ int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, v
  *   build_rows: rows [row_begin, row_end) of the float64 train-train kernel (all columns);
  *               (0, n) takes the symmetric path (lower tiles computed once, mirrored)
  *   factor    : A32 = float32(K) + reg I, blocked lower Cholesky in place (panels on the float32 MFMA, the large
- *               trailing updates as split-float16 MFMA products with float32 accumulation)
+ *               trailing updates as split-float16 MFMA products with float32 accumulation).  The factor is the
+ *               preconditioner of the float64 solves, not the solver: when the float32 factorisation breaks down
+ *               (pivots at the rounding-noise floor, cond(K + reg I) * eps32 >> 1) it is rebuilt from the float64
+ *               kernel with a 16x larger diagonal shift, up to four times -- more CG iterations, same alpha and
+ *               refined covariances.  nngp_model_factor_shift returns the shift in use (= reg normally); the call
+ *               waits for the factorisation (one 4-byte read-back of the clamped-pivot count).
  *   solve     : alpha = (K + reg I)^-1 Y by CG on the float64 kernel, preconditioned by the
- *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-10).
+ *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-10; 60 is scaled by
+ *               sqrt(shift / reg) when the factor carries a raised shift).
  *               The call records the request; the CG itself runs on the model's own high-priority stream when alpha
  *               is first needed -- nngp_model_alpha / _info (which then block for it), or inside nngp_model_predict
  *               after the covariance work has been enqueued, so that it overlaps it.                          */
 int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_t n, void* stream);
 int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, void* stream);
 int nngp_model_factor(nngp_model* m, void* stream);
+double nngp_model_factor_shift(nngp_model* m);
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream);
 /* Appends b training rows (device pointers x_new [b, d], y_new [b, ny]) to a fitted model: the kernel rows of the new
  * queries are built and the float32 factor is EXTENDED (L10 by a blocked triangular solve against the existing factor,

@@ -118,6 +118,11 @@ class GPModel:
         _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 
+    def factor_shift(self) -> float:
+        """Diagonal shift of the float32 factor's input: the regulariser, or 16^k times it when the float32
+        factorisation of K + reg I broke down and was redone (the factor is only the preconditioner)."""
+        return float(self.lib.nngp_model_factor_shift(self.handle))
+
     def cov_iters(self) -> int:
         """CG iterations the last predict spent continuing the covariance solve beyond the fixed sweeps (levels >= 2 do
         that when the float32 factor is a weak preconditioner; 0 = the fixed sweeps were enough)."""
