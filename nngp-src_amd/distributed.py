@@ -186,6 +186,18 @@ def distributed_factor(model, group=None, nb: int = None):
     return model
 
 
+def _any_rank(flag: bool, group=None) -> bool:
+    """Logical OR of a host flag over the ranks."""
+    import torch
+    dist = _dist()
+    if world_size() == 1:
+        return bool(flag)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
+
+
 def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True):
     """GPModel fit with the kernel build sharded over ranks: build own rows -> all-gather -> replicated
     factor + solve.  The model must have been created with n_cap >= world * ceil(n / world)."""
@@ -207,6 +219,11 @@ def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True
     t2 = ev()
     if world > 1 and distributed_cholesky:
         distributed_factor(model, group)
+        # float32 breakdown (clamped pivots on any rank's block columns: cond(K + reg I) * eps32 >> 1): every rank holds
+        # the whole float64 kernel, so all of them redo the factor on their own GPU, where nngp_model_factor raises the
+        # preconditioner shift until the factorisation goes through (one 4-byte status reduction per fit)
+        if _any_rank(model.info()["clamped_pivots"] > 0, group):
+            model.factor()
     else:
         model.factor()
     t3 = ev()

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, d, out_dir):
+def _worker(rank, world, port, n, d, out_dir, hard=False):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -37,10 +37,14 @@ def _worker(rank, world, port, n, d, out_dir):
         x, y = synth.synthetic_queries(n, d, seed=0)
         xt, _ = synth.synthetic_queries(64, d, seed=1)
         n_cap = distributed.row_chunk(n, world) * world
-        model = GPModel(n_cap, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3)
+        if hard:  # cond(K + reg I) * eps32 >> 1: the block-cyclic float32 factorisation clamps pivots
+            model = GPModel(n_cap, d, [1.63] * 4, [0.0] * 4, diag_reg=10.0, diag_reg_absolute_scale=True)
+        else:
+            model = GPModel(n_cap, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3)
         distributed.sharded_fit(model, x, y)
         info = model.info()
         assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+        assert (model.factor_shift() > info["reg"]) == hard
         mean, var = model.predict(xt, cov="diag")
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean, var=var, alpha=model.alpha().cpu().numpy())
     finally:
@@ -64,3 +68,22 @@ def test_two_rank_fit_matches_single_rank(tmp_path, n):
         assert np.linalg.norm(g["alpha"] - a0) / np.linalg.norm(a0) < 1e-9
         assert np.linalg.norm(g["mean"] - m0) / np.linalg.norm(m0) < 1e-9
         np.testing.assert_allclose(g["var"], v0, rtol=1e-6)
+
+
+def test_two_rank_fit_survives_a_float32_breakdown(tmp_path):
+    """The ill-conditioned fit of test_gpu_parity (d = 2, 4-layer, absolute diag_reg = 10): the ranks agree that the
+    block-cyclic factorisation broke down, refactor with a raised preconditioner shift, and still deliver the
+    single-rank posterior."""
+    n, d = 3000, 2
+    sys.path.insert(0, ROOT)
+    from nngp_src_amd import synth
+    from nngp_src_amd.model import GPModel
+    mp.spawn(_worker, args=(2, _free_port(), n, d, str(tmp_path), True), nprocs=2, join=True)
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(64, d, seed=1)
+    ref = GPModel(n, d, [1.63] * 4, [0.0] * 4, diag_reg=10.0, diag_reg_absolute_scale=True).fit(x, y)
+    m0, v0 = ref.predict(xt, cov="diag")
+    for r in range(2):
+        g = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.linalg.norm(g["mean"] - m0) / np.linalg.norm(m0) < 1e-7
+        np.testing.assert_allclose(g["var"], v0, rtol=1e-5)
