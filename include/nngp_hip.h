@@ -164,11 +164,22 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  * z.r is too large for its second-order error to be small (a loose lower bound: the backstop when the alpha solve says
  * nothing, e.g. y = 0) -- and then continues the rows by preconditioned
  * CG (one float64 product + one pair of solves per iteration, each row with its own scalars) until every row's step
- * lowers e^T A e by less than 1e-8 of its variance, and forms the covariance again.  The check costs one 4-byte
- * read-back per predict call with a covariance (the call then waits for its own covariance work);
+ * lowers e^T A e by less than 1e-8 of its variance, and forms the covariance again.  The row check needs a 4-byte
+ * read-back (the call then waits for its own covariance work); it is made only when the alpha solve took < 3 iterations;
  * nngp_model_cov_iters returns the iterations the last predict spent there (0: the fixed sweeps were enough). */
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps);
 int nngp_model_cov_iters(nngp_model* m);
+
+/* Serving mode (the reference's Estimator keeps its factor and solves per query batch: estimator.py:34-67).  Builds the
+ * explicit float64 inverse X = (K + reg I)^-1 once per fit -- rows of the identity, 1024 at a time, through the
+ * float32 solves + float64 corrections above (to CG convergence when the factor is a weak preconditioner), then
+ * symmetrised; N^2 doubles of HBM.  Afterwards nngp_model_predict at levels >= 1 takes Z = K_td X (one float64
+ * product, no triangular solves) in place of the float32 solves + sweeps and applies the same second-order formulas
+ * (diag: K_tt - (2 z.k - z^T A z); full: K_tt - sym(Z (K_td + R)^T)) -- Z K_dt alone would not do: k^T X k cancels to
+ * the variance from terms 1e3..1e6 larger, and no float64 inverse is that accurate.  NNGP posterior only (no-op for
+ * NTK, whose covariance has no such formula).  Any later set_train / factor / append drops the inverse.
+ * Cost: ~N/1024 covariance-sized solves. */
+int nngp_model_prepare_serving(nngp_model* m, void* stream);
 
 /* ---- N2: native query-line encoder (host code; replaces the per-line Python of estimator/encoder.py:59-97,187-250
  * and QuerySampler.py:157-221) --------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_append", "nngp_model_kernel_buffer", "nngp_model_info",
-    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_factor_shift", "nngp_potrf_f32", "nngp_gemm_nt_f32",
+    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_factor_shift", "nngp_model_prepare_serving", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode",
 )
@@ -91,6 +91,7 @@ def load():
     lib.nngp_encoder_encode.argtypes = [vp, ctypes.c_char_p, i64, i32, vp, vp, i64, ctypes.POINTER(i64)]
     lib.nngp_model_set_refine.argtypes = [vp, i32]
     lib.nngp_model_cov_iters.argtypes = [vp]
+    lib.nngp_model_prepare_serving.argtypes = [vp, vp]
     lib.nngp_model_factor_shift.argtypes = [vp]
     lib.nngp_model_factor_shift.restype = ctypes.c_double
     lib.nngp_model_cov_iters.restype = ctypes.c_int

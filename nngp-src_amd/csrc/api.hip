@@ -99,6 +99,11 @@ struct nngp_model {
     double* z64 = nullptr;       // [refine_cap, np_cap]  Z ~ K_td (K + reg I)^-1
     double* r64 = nullptr;       // [refine_cap, np_cap]  residual / product workspace
     double* covp64 = nullptr;    // [fullp, fullp] padded covariance
+    // serving mode (nngp_model_prepare_serving): explicit float64 (K + reg I)^-1, refined to float64 accuracy once per fit;
+    // predict then needs one float64 product per query batch instead of blocked solves + correction sweeps
+    double* ainv64 = nullptr;    // [np, np] compact (ld = np at the time it was built)
+    bool serving_ready = false;
+    bool serving_weak = false;   // built from a weak preconditioner: predict adds one correction step
     RowsPcg rows{};              // per-row CG that continues the correction sweeps when the float32 factor is a weak preconditioner
     int64_t rows_pq_cap = 0;     // row capacity of rows.p / rows.q (allocated when a continuation first runs)
     int cov_iters = 0;           // iterations of the last continuation (0: the fixed sweeps were enough)
@@ -137,6 +142,7 @@ struct nngp_model {
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
+        dev_free(ainv64);
         dev_free(rows.p); dev_free(rows.q); dev_free(rows.rho); dev_free(rows.coef); dev_free(rows.tol); dev_free(rows.delta);
         dev_free(rows.var); dev_free(rows.state); dev_free(rows.live);
         if (rows.host) (void)hipHostFree(rows.host);
@@ -273,9 +279,12 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
 }
 
 // the factor has float16-split copies (look-ahead factorisation) and the caller did not ask for the float32 path
+// and the block of right-hand sides is large enough for the 256-row tiles of the float16 GEMM to pay (measured, ms per
+// diag-variance call at level 2, float16 / float32 solves -- N = 10800: M = 128: 6.5 / 5.6, 512: 9.1 / 8.8, 1024: 11.5 / 12.9;
+// N = 32768: M = 128: 21.8 / 20.1, 256: 29.3 / 30.6, 512: 40.6 / 51.5)
 bool use_split_solves(const nngp_model* m, int64_t mp) {
     return m->split.l_ready && m->split.planes_b != nullptr && mp <= m->split.mb_cap && m->tri.bs == m->split.k_cap &&
-           g_debug[7] == 0;
+           g_debug[7] == 0 && mp >= 256 && mp * m->np >= 7000000;
 }
 
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
@@ -517,6 +526,7 @@ int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_
     m->np = round_up(n, TB);
     m->built = m->factored = m->solved = false;
     m->solve_pending = false;
+    m->serving_ready = false;
     NNGP_HIP_CHECK(hipMemcpyAsync(m->x, x, sizeof(double) * n * m->d, hipMemcpyDeviceToDevice, s));
     NNGP_HIP_CHECK(hipMemcpyAsync(m->y, y, sizeof(double) * n * m->ny, hipMemcpyDeviceToDevice, s));
     NNGP_TRY(launch_row_sqnorm(m->x, n, m->d, m->q, s));
@@ -572,6 +582,7 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
     m->solve_pending = false;
+    m->serving_ready = false;
     m->split.l_ready = m->split.lt_ready = false;  // set again by the look-ahead factorisation / factor_end
     m->split.split_panel = -1;
     return 0;
@@ -683,6 +694,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     m->np = np1;
     m->solved = false;
     m->solve_pending = false;
+    m->serving_ready = false;
     // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
@@ -805,6 +817,46 @@ int nngp_model_set_refine(nngp_model* m, int32_t sweeps) {
     return 0;
 }
 
+// Serving mode (the reference's Estimator keeps its Cholesky factor and calls cho_solve per query
+// batch, estimator.py:34-67).  Builds X = (K + reg I)^-1 explicitly in float64: rows of the identity, 1024 at a time,
+// through the same float32-solve + float64-correction machinery as the covariance (two sweeps; by CG to convergence when
+// the factor is a weak preconditioner), then X <- (X + X^T) / 2.  Cost ~ N/1024 covariance-sized solves, once per fit;
+// afterwards predict forms Z = K_td X with ONE float64 product and no solves.
+int nngp_model_prepare_serving(nngp_model* m, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->solved, "prepare_serving: fit the model first");
+    if (m->get != NNGP_GET_NNGP) return 0;  // the NTK covariance has no second-order formula to absorb the inverse's error
+    NNGP_TRY(run_pending_solve(m, s, true));  // its iteration count says how good the preconditioner is
+    const int64_t n = m->n, np = m->np;
+    const int64_t blk = np < 1024 ? np : 1024;
+    NNGP_TRY(ensure_predict_capacity(m, blk, true));
+    NNGP_TRY(ensure_refine_capacity(m, blk));
+    if (!use_split_solves(m, blk)) NNGP_TRY(ensure_lt(m, s));
+    if (m->ainv64 == nullptr) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        NNGP_TRY(dev_alloc(&m->ainv64, m->np_cap * m->np_cap));
+    }
+    const bool weak = m->iters >= 8 || m->reg_fac > m->reg;
+    const double shift = (m->reg > 0.0 && m->reg_fac > m->reg) ? sqrt(m->reg_fac / m->reg) : 1.0;
+    for (int64_t r0 = 0; r0 < n; r0 += blk) {
+        const int64_t rows = (n - r0 < blk) ? n - r0 : blk, rp = round_up(rows, TB);
+        NNGP_TRY(launch_identity_rows(m->ktd64, np, np, r0, rows, rp, s));
+        // three sweeps: the rows' errors add up coherently in Z = K_td X (two left 1.4e-3 in the variance at N = 32768)
+        NNGP_TRY(refined_solve_rows(m, m->ktd64, rp, 3, weak, s));
+        if (weak) {  // tolerance relative to the row's energy z.e = X_ii
+            NNGP_TRY(launch_rowdot_f64(m->z64, m->ktd64, 1.0, nullptr, np, rows, np, nullptr, 1.0, m->rows.delta, s));
+            NNGP_TRY(launch_rows_prepare(nullptr, nullptr, nullptr, m->rows.delta, 1, 0.0, rows, m->rows.tol, m->rows.live + 1, s));
+            NNGP_TRY(rows_pcg_continue(m, rp, (int)fmin(1000.0, 80.0 * shift), s));
+        }
+        NNGP_HIP_CHECK(hipMemcpyAsync(m->ainv64 + r0 * np, m->z64, sizeof(double) * rows * np, hipMemcpyDeviceToDevice, s));
+    }
+    if (np > n) NNGP_HIP_CHECK(hipMemsetAsync(m->ainv64 + n * np, 0, sizeof(double) * (np - n) * np, s));
+    NNGP_TRY(launch_symmetrize_f64(m->ainv64, np, np, s));
+    m->serving_ready = true;
+    m->serving_weak = weak;
+    return 0;
+}
+
 int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode, double* mean,
                        double* var_or_cov, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -879,13 +931,32 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         return launch_cov_finish(m->ktt64, mp, m->vvt32, mp, mt, var_or_cov, s);
     }
 
-    if (!use_split_solves(m, mp)) NNGP_TRY(ensure_lt(m, s));  // float32 L^T: only the float32 solve path reads it
+    const bool serving = m->serving_ready && !is_ntk;  // Z = K_td X with the explicit float64 inverse: one product, no solves
+    if (!serving && !use_split_solves(m, mp)) NNGP_TRY(ensure_lt(m, s));  // float32 L^T: only the float32 solve path reads it
     NNGP_TRY(ensure_refine_capacity(m, mp));
+    // z64 ~ rows of K_td (K + reg I)^-1 [and r64 = their residual]: float32 solves + float64 sweeps, or -- serving mode --
+    // one product with the explicit inverse.  Either way z64 only has to be GOOD, not exact: the second-order formulas
+    // below square its error.  (K_td X alone would not do: k^T X k cancels to the variance from terms 1e3..1e6 larger,
+    // and no float64 inverse is accurate to that.)
+    auto solve_rows = [&](int sweeps, bool final_residual) -> int {
+        if (!serving) return refined_solve_rows(m, ktd, mp, sweeps, final_residual, s);
+        NNGP_TRY(launch_gemm_nt_f64(m->z64, np, nullptr, 0, ktd, np, m->ainv64, np, mp, np, np, 1.0, 0.0, s));
+        if (m->serving_weak) {  // ill-conditioned fit: X is less accurate; one correction step with X as the solver
+            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
+            NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+            NNGP_TRY(launch_gemm_nt_f64(m->z64, np, m->z64, np, m->r64, np, m->ainv64, np, mp, np, np, 1.0, 1.0, s));
+        }
+        if (final_residual) {
+            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
+            NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+        }
+        return 0;
+    };
     if (!is_ntk) {
         // NNGP: cov_ij = K_tt,ij - k_i^T A^-1 k_j with Z ~ K_td A^-1 (float32 solve + float64 correction sweeps).
         //   level 1: one sweep, cov = K_tt - sym(Z K_dt)  (error ~ rho * float32 error); diag only: see below
         //   level L >= 2: L-1 sweeps, then with R = K_td - Z A:  k_i^T A^-1 k_j = sym(z_i . (k_j + r_j)) + O(err^2)
-        const int level = m->var_refine;
+        const int level = (serving && m->var_refine < 2) ? 2 : m->var_refine;  // the inverse needs the second-order formula
         const bool second_order = level >= 2;
         if (!full && level == 1) {
             // diag, one float64 product: with z0 from the float32 factor, r0 = k - A z0 and d = M^-1 r0,
@@ -902,22 +973,35 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));  // d
             return launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, var_or_cov, -1.0, var_or_cov, s);
         }
+        if (!full && serving && mt <= (np <= 16384 ? 32 : 16) && !m->serving_weak) {
+            // a handful of queries against the explicit inverse: two passes over N x N float64 matrices (X, then K) per
+            // group of 8 queries, both HBM-bound; var = K_tt - (2 z.k - z^T (K + reg I) z).  (Measured, ms per call,
+            // streamed groups / 128-row MFMA GEMM -- N = 10800: 8 queries 0.62 / 3.06; N = 32768: 4.07 / 9.29.)
+            for (int64_t g = 0; g < mt; g += 8) {
+                const int64_t gm = (mt - g < 8) ? mt - g : 8;
+                NNGP_TRY(launch_skinny_nt_f64(m->z64 + g * np, np, nullptr, 0, ktd + g * np, np, m->ainv64, np, gm, np, np, 1.0, 0.0, s));
+                NNGP_TRY(launch_skinny_nt_f64(m->r64 + g * np, np, nullptr, 0, m->z64 + g * np, np, m->k64, m->ld, gm, np, np, 1.0, 0.0, s));
+            }
+            NNGP_TRY(launch_axpby_mat(m->r64, -1.0, m->z64, -m->reg, np, mt, np, s));
+            return launch_rowdot_f64(m->z64, ktd, 2.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s);
+        }
         if (!full && second_order) {
             // diag only: z.(k + r) = 2 z.k - z^T (K + reg I) z, and the quadratic form needs only the lower triangle of
             // the symmetric K: W = 2 Z strict_lower_blocks(K) + Z diag_blocks(K) -- HALF the float64 product that the
             // full residual costs (kmode 1 / 2 of the float64 GEMM), then var = K_tt - z.(2 k - W - reg z)
-            NNGP_TRY(refined_solve_rows(m, ktd, mp, level - 1, false, s));
+            NNGP_TRY(solve_rows(level - 1, false));
             NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->k64, m->ld, mp, np, np, 2.0, 0.0, s, 1));
             NNGP_TRY(launch_gemm_nt_f64(m->r64, np, m->r64, np, m->z64, np, m->k64, m->ld, mp, np, np, 1.0, 1.0, s, 2));
             NNGP_TRY(launch_axpby_mat(m->r64, -1.0, m->z64, -m->reg, np, mp, np, s));
             NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 2.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
             // delta = z.k - z^T A z: the first-order term that the formula above cancels (cov_adaptive reads the flags)
             NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s));
+            if (serving) return 0;  // the inverse was refined to convergence when it was built
             check_kind = 1;
             return launch_rows_prepare(m->rows.delta, m->tt_diag, var_or_cov, nullptr, 0, kFlagThr, mt, m->rows.tol,
                                        m->rows.live + 1, s);
         }
-        NNGP_TRY(refined_solve_rows(m, ktd, mp, second_order ? level - 1 : 1, second_order, s));
+        NNGP_TRY(solve_rows(second_order ? level - 1 : 1, second_order));
         if (!full)
             return launch_rowdot_f64(m->z64, ktd, 1.0, second_order ? m->r64 : nullptr, np, mt, np, m->tt_diag, -1.0,
                                      var_or_cov, s);
@@ -927,7 +1011,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s));
             NNGP_TRY(launch_rows_prepare(m->rows.delta, m->tt_diag, m->rows.var, nullptr, 0, kFlagThr, mt, m->rows.tol,
                                          m->rows.live + 1, s));
-            check_kind = 2;
+            check_kind = serving ? 0 : 2;
             NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, 1.0, np, mp, np, s));  // G = K_td + R
             g = m->r64;
         }
@@ -982,7 +1066,9 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         // tests/test_gpu_parity.py (N <= 5200): <= 5: <= 1e-7, 6: <= 1e-5, 7: <= 5e-5, >= 9: up to 8e-2; the bench sizes
         // need 5 (N = 32768) and 6 (N = 65536).  NTK covariance has no second-order formula: stricter.
         bool weak = m->iters >= (is_ntk ? 4 : 8) || m->reg_fac > m->reg;
-        if (!weak && check_kind != 3) {
+        // the row flag is the backstop for fits whose alpha solve says nothing (it converged in < 3 iterations, e.g.
+        // y = 0); otherwise the iteration count decides and the call stays asynchronous
+        if (!weak && check_kind != 3 && m->iters < 3) {
             NNGP_HIP_CHECK(hipMemcpyAsync(m->rows.host + 1, m->rows.live + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             NNGP_HIP_CHECK(hipStreamSynchronize(s));
             weak = m->rows.host[1] > 0;

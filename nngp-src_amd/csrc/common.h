@@ -203,6 +203,10 @@ int launch_axpby_mat(double* r, double a, const double* k, double b, int64_t ld,
 int launch_rowdot_f64(const double* z, const double* k, double kscale, const double* r, int64_t ld, int64_t rows,
                       int64_t cols, const double* base, double sign, double* out, hipStream_t s);
 int launch_copy_mat_f64(const double* src, int64_t lds, double* dst, int64_t m, hipStream_t s);
+int launch_skinny_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                         const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, hipStream_t s);
+int launch_identity_rows(double* e, int64_t ld, int64_t cols, int64_t r0, int64_t rows, int64_t rows_p, hipStream_t s);
+int launch_symmetrize_f64(double* a, int64_t ld, int64_t n, hipStream_t s);
 // per-row preconditioned CG over [rows, cols] blocks (api.hip: rows_pcg_continue)
 struct RowsPcg {
     int64_t cap = 0;          // padded row capacity

@@ -239,6 +239,72 @@ __global__ __launch_bounds__(256) void k_rows_axpy2(double* __restrict__ z, doub
     r[row * ld + c] = fma(-a, q[row * ld + c], r[row * ld + c]);
 }
 
+// rows [r0, r0 + rows) of the identity, zero-padded to [rows_p, cols]
+__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ e, int64_t ld, int64_t cols, int64_t r0, int64_t rows) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) e[row * ld + c] = (row < rows && c == r0 + row) ? 1.0 : 0.0;
+}
+
+// a <- (a + a^T) / 2 in place, [n, n]; one thread per pair (i > j)
+__global__ __launch_bounds__(256) void k_symmetrize_f64(double* __restrict__ a, int64_t ld, int64_t n, int64_t row0) {
+    const int64_t i = row0 + blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= i || i >= n) return;
+    const double v = 0.5 * (a[i * ld + j] + a[j * ld + i]);
+    a[i * ld + j] = v;
+    a[j * ld + i] = v;
+}
+
+// C[r][j] = alpha * sum_i A[r][i] B[j][i] + beta * Cin[r][j] for a handful of rows r < M (M <= 8): serving-mode products
+// Z = K_td X and Z K for one or a few queries.  The rows of B (N x N float64) are streamed once, four per workgroup --
+// HBM-bound, where the 128-row MFMA GEMM would spend 128/M times the flops on padding.  A comes from L2.
+template <int M>
+__global__ __launch_bounds__(256) void k_skinny_nt_f64(double* __restrict__ C, int64_t ldc, const double* __restrict__ Cin,
+                                                       int64_t ldcin, const double* __restrict__ A, int64_t lda,
+                                                       const double* __restrict__ B, int64_t ldb, int64_t n, int64_t k,
+                                                       double alpha, double beta) {
+    constexpr int JB = 4;
+    const int64_t j0 = (int64_t)blockIdx.x * JB;
+    double acc[M][JB];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) acc[r][jj] = 0.0;
+    const double* brow[JB];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) brow[jj] = B + (j0 + jj < n ? j0 + jj : n - 1) * ldb;
+    for (int64_t i = (int64_t)threadIdx.x * 2; i < k; i += 512) {
+        double2 b[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) b[jj] = *reinterpret_cast<const double2*>(brow[jj] + i);
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const double2 a = *reinterpret_cast<const double2*>(A + r * lda + i);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[r][jj] = fma(a.x, b[jj].x, fma(a.y, b[jj].y, acc[r][jj]));
+        }
+    }
+    __shared__ double red[4][M * JB];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            double v = acc[r][jj];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][r * JB + jj] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < M * JB) {
+        const int r = threadIdx.x / JB, jj = threadIdx.x % JB;
+        if (j0 + jj < n) {
+            double v = alpha * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (Cin != nullptr) v = fma(beta, Cin[r * ldcin + j0 + jj], v);
+            C[r * ldc + j0 + jj] = v;
+        }
+    }
+}
+
 // dst[m, m] (dense) = (src + src^T) / 2 of src[m, m] (leading dimension lds).  The symmetric part is where the
 // first-order error of the refined solve cancels for off-diagonal covariance entries as well.
 __global__ __launch_bounds__(256) void k_copy_mat_f64(const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
@@ -422,6 +488,35 @@ int launch_rows_axpy2(double* z, double* r, const double* p, const double* q, in
         hipLaunchKernelGGL(k_rows_axpy2, dim3((unsigned)((cols + 255) / 256), (unsigned)nr), dim3(256), 0, s, z + r0 * ld,
                            r + r0 * ld, p + r0 * ld, q + r0 * ld, ld, cols, w.coef + r0);
     }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_identity_rows(double* e, int64_t ld, int64_t cols, int64_t r0, int64_t rows, int64_t rows_p, hipStream_t s) {
+    NNGP_REQUIRE(rows_p <= 65535, "identity_rows: at most 65535 rows");
+    hipLaunchKernelGGL(k_identity_rows, dim3((unsigned)((cols + 255) / 256), (unsigned)rows_p), dim3(256), 0, s, e, ld, cols, r0, rows);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_symmetrize_f64(double* a, int64_t ld, int64_t n, hipStream_t s) {
+    for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+        const int64_t nr = (n - r0 < 65535) ? n - r0 : 65535;
+        hipLaunchKernelGGL(k_symmetrize_f64, dim3((unsigned)((r0 + nr + 255) / 256), (unsigned)nr), dim3(256), 0, s, a, ld, n, r0);
+    }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// rows of A / C / Cin up to the next power of two >= m must be addressable (they are: the buffers are padded to 128 rows)
+int launch_skinny_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                         const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, hipStream_t s) {
+    NNGP_REQUIRE(m >= 1 && m <= 8 && n > 0 && k > 0 && k % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0, "skinny_nt_f64: bad shape");
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    if (m == 1) hipLaunchKernelGGL(k_skinny_nt_f64<1>, grid, block, 0, s, c, ldc, cin, ldcin, a, lda, b, ldb, n, k, alpha, beta);
+    else if (m == 2) hipLaunchKernelGGL(k_skinny_nt_f64<2>, grid, block, 0, s, c, ldc, cin, ldcin, a, lda, b, ldb, n, k, alpha, beta);
+    else if (m <= 4) hipLaunchKernelGGL(k_skinny_nt_f64<4>, grid, block, 0, s, c, ldc, cin, ldcin, a, lda, b, ldb, n, k, alpha, beta);
+    else hipLaunchKernelGGL(k_skinny_nt_f64<8>, grid, block, 0, s, c, ldc, cin, ldcin, a, lda, b, ldb, n, k, alpha, beta);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -19,12 +19,13 @@ from .batching import batch
 class Estimator(object):
     def __init__(self, schema_name: str, data_path: str, train_query_path: str, chunk_size: int = 64,
                  use_aux: bool = False, q_error_threshold: float = 100.0, coef_var_threshold: float = 1.0,
-                 encoder=None, kernel_type: str = "nngp"):
+                 encoder=None, kernel_type: str = "nngp", serving: bool = True):
         self.schema_name = schema_name
         self.data_path = data_path
         self.train_query_path = train_query_path
         self.chunk_size = chunk_size
         self.kernel_type = kernel_type
+        self.serving = serving  # load_model also builds the explicit float64 inverse: predict = one product per batch
         print("loading schema and training data ... This may take seconds ...")
         if encoder is None:
             from .schemas import load_training_schema_data
@@ -47,6 +48,8 @@ class Estimator(object):
 
     def load_model(self):
         model = self.predict_fn.model_for(self.kernel_type)  # kernel build + Cholesky + alpha, cached in HBM
+        if self.serving:
+            model.prepare_serving()
         n = self.X_train.shape[0]
         print((n, model.ny), (n, n))  # the shapes the reference prints (estimator.py:39)
         print("Model construction complete.")

@@ -118,6 +118,12 @@ class GPModel:
         _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 
+    def prepare_serving(self):
+        """Build the explicit float64 inverse of K + reg I once (``nngp_model_prepare_serving``): later ``predict`` calls
+        cost one float64 product instead of blocked solves and correction sweeps.  Dropped by fit / append."""
+        _lib.check(self.lib.nngp_model_prepare_serving(self.handle, _lib.stream_ptr()))
+        return self
+
     def factor_shift(self) -> float:
         """Diagonal shift of the float32 factor's input: the regulariser, or 16^k times it when the float32
         factorisation of K + reg I broke down and was redone (the factor is only the preconditioner)."""

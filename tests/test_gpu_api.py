@@ -177,3 +177,42 @@ def test_append_rows_matches_full_refit(n0, b, ncap):
         assert torch.equal(k_inc[:cur, :cur], k_inc[:cur, :cur].T)
         ref.close()
     inc.close()
+
+
+@pytest.mark.parametrize("get,n,d,reg", [("nngp", 2500, 20, 1e-3), ("ntk", 1300, 16, 1e-3), ("nngp", 2706, 3, 1e-4)])
+def test_serving_mode_matches_the_solve_path(get, n, d, reg):
+    """nngp_model_prepare_serving: predictions through the explicit float64 inverse against the solve path at level 3
+    (diag, full, x_test=None), on a well-conditioned fit of each kernel and on the ill-conditioned NNGP fit of the sweep;
+    append drops the inverse."""
+    from nngp_src_amd import synth
+    from nngp_src_amd.model import GPModel
+    x, y = synth.synthetic_queries(n + 40, d, seed=6)
+    xt, _ = synth.synthetic_queries(150, d, seed=106)
+    arch = ([0.96] * 4, [0.05] * 4) if d == 3 else ([1.0] * 3, [0.0] * 3)
+    model = GPModel(n + 40, d, arch[0], arch[1], get=get, diag_reg=reg).fit(x[:n], y[:n])
+    model.set_refine(3)
+    mean0, var0 = model.predict(xt, cov="diag")
+    _, cov0 = model.predict(xt[:40], cov="full")
+    mtr0, vtr0 = model.predict(None, cov="diag")
+    model.prepare_serving()
+    model.set_refine(2)
+    mean1, var1 = model.predict(xt, cov="diag")
+    assert model.cov_iters() == 0
+    _, cov1 = model.predict(xt[:40], cov="full")
+    mtr1, vtr1 = model.predict(None, cov="diag")
+    assert np.array_equal(mean1, mean0) and np.array_equal(mtr1, mtr0)
+    np.testing.assert_allclose(var1, var0, rtol=2e-6)
+    assert np.abs(cov1 - cov0).max() <= 2e-6 * np.abs(np.diag(cov0)).max()
+    assert np.array_equal(cov1, cov1.T)
+    np.testing.assert_allclose(vtr1, vtr0, rtol=1e-4, atol=1e-9 * np.abs(vtr0).max())
+    for few in (1, 3, 8, 13):  # a handful of queries: the streaming (skinny) products instead of the 128-row MFMA GEMM
+        mean_f, var_f = model.predict(xt[:few], cov="diag")
+        assert np.array_equal(mean_f, mean0[:few])
+        np.testing.assert_allclose(var_f, var0[:few], rtol=2e-6)
+    # the inverse belongs to the fit it was built from
+    model.append(x[n:], y[n:])
+    ref = GPModel(n + 40, d, arch[0], arch[1], get=get, diag_reg=reg).fit(x, y)
+    _, var2 = model.predict(xt, cov="diag")
+    _, var3 = ref.predict(xt, cov="diag")
+    np.testing.assert_allclose(var2, var3, rtol=1e-5, atol=1e-9 * np.abs(var3).max())
+    model.close(); ref.close()

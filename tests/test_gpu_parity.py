@@ -522,7 +522,8 @@ def test_full_forest_run_against_c_oracle(golden_dir):
     print("forest full run: cg_iters=%d, q-error median %.4f mean %.3f" % (info["refine_iters"], pa["median"], pa["mean"]))
 
 
-@pytest.mark.parametrize("n,m,d,n_relu,ny", [(4100, 130, 7, 1, 1), (4224, 1, 20, 2, 2), (5003, 1000, 12, 1, 1), (6143, 257, 20, 3, 1)])
+@pytest.mark.parametrize("n,m,d,n_relu,ny", [(4100, 130, 7, 1, 1), (4224, 1, 20, 2, 2), (5003, 1000, 12, 1, 1), (6143, 257, 20, 3, 1),
+                                             (6143, 1500, 20, 1, 1)])  # the last one is large enough for the float16-pipe solves
 def test_lookahead_sizes_not_multiples_of_the_blocks(n, m, d, n_relu, ny):
     """N just above the look-ahead threshold and not a multiple of 128 / 1024, M not a multiple of 128: the tail block
     column, the split copies of the factor and the float16-pipe solves of the posterior against the float64 C oracle."""
