@@ -907,7 +907,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // Row flag: a LOWER bound of the remaining relative variance error above this value (debug key 6 = e >= 2: 10^-e).
     // The bound is loose -- measured 1e-10 where the error is 4e-7 (N = 32768, scripts/flag_study.py) -- so it is only the
     // backstop for fits whose alpha solve says nothing about the conditioning (e.g. y = 0 converges at once).
-    const double kFlagThr = g_debug[6] >= 2 ? pow(10.0, -(double)g_debug[6]) : 1e-8;
+    const double kFlagThr = (g_debug[6] >= 2 && g_debug[6] <= 30) ? pow(10.0, -(double)g_debug[6]) : 1e-8;
     auto cov_part = [&]() -> int {
     if (full) NNGP_TRY(ensure_full_cov_capacity(m, mt));
     NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));  // NNGP K(x_t, x_t)

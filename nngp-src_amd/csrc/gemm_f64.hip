@@ -27,15 +27,16 @@ __device__ __forceinline__ int lds_off64(int row, int ch) { return row * 128 + (
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, const double* Cin, int64_t ldcin,
                                                         const double* A, int64_t lda, const double* B, int64_t ldb,
                                                         int tiles_m, int nk, double alpha, double beta, int kmode,
-                                                        int tiles_n) {
+                                                        int tiles_n, int ksplit, double* part, int64_t part_stride) {
     __shared__ __attribute__((aligned(16))) double smem[2 * DSTAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // row tile is the fast index: the workgroups that share one 128-row panel of B (the big symmetric kernel matrix)
     // are dispatched together, so the panel is fetched from HBM once and served from L2 / Infinity Cache after that
-    const int bi = blockIdx.x % tiles_m;
-    int bj = blockIdx.x / tiles_m;
+    const int tile = blockIdx.x % (tiles_m * tiles_n), kp = blockIdx.x / (tiles_m * tiles_n);
+    const int bi = tile % tiles_m;
+    int bj = tile / tiles_m;
     // kmode (B square and symmetric, quadratic forms z^T B z from its lower triangle only): 1 = only the k blocks
     // strictly left of the column tile's own 128-block, 2 = only that diagonal block.  The long tiles go first.
     int t0 = 0, t1 = nk;
@@ -45,6 +46,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
     } else if (kmode == 2) {
         t0 = bj * (DBN / DBK);
         t1 = t0 + DBN / DBK;
+    }
+    if (ksplit > 1) {  // split K: this workgroup's share of [t0, t1); its tile goes to part[kp] (summed by k_splitk_reduce)
+        const int len = (t1 - t0 + ksplit - 1) / ksplit;
+        t0 += kp * len;
+        if (t0 + len < t1) t1 = t0 + len;
     }
     const double* Ab = A + (int64_t)bi * DBM * lda;
     const double* Bb = B + (int64_t)bj * DBN * ldb;
@@ -110,6 +116,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
 
     const int64_t row_base = (int64_t)bi * DBM + wm * 64;
     const int64_t col_base = (int64_t)bj * DBN + wn * 64;
+    if (ksplit > 1) {
+        double* P = part + (int64_t)kp * part_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    P[(row_base + i * 16 + g + 4 * r) * ldc + col_base + j * 16 + r16] = acc[i][j][r];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -129,6 +146,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
         }
 }
 
+// C = beta * Cin + alpha * sum_p part[p]   (fixed summation order: the split-K product is deterministic)
+__global__ __launch_bounds__(256) void k_splitk_reduce(double* __restrict__ C, int64_t ldc, const double* __restrict__ Cin,
+                                                       int64_t ldcin, const double* __restrict__ part, int64_t part_stride,
+                                                       int ksplit, int64_t n, double alpha, double beta) {
+    const int64_t row = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    double v = 0.0;
+    for (int p = 0; p < ksplit; ++p) v += part[(int64_t)p * part_stride + row * ldc + c];
+    v *= alpha;
+    if (beta != 0.0) v = fma(beta, Cin[row * ldcin + c], v);
+    C[row * ldc + c] = v;
+}
+
 }  // namespace
 
 int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
@@ -144,10 +175,34 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
     NNGP_REQUIRE(lda >= k && ldb >= k && ldc >= n && (beta == 0.0 || (cin != nullptr && ldcin >= n)),
                  "gemm_nt_f64: leading dimension too small");
     const int64_t tm = m / DBM, tn = n / DBN;
-    NNGP_REQUIRE(tm * tn < 2147483647LL, "gemm_nt_f64: grid too large");
-    hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
-                       a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn);
+    NNGP_REQUIRE(tm * tn < 2147483647LL / 8, "gemm_nt_f64: grid too large");
+    // Few tiles and a long K (a small block of queries against the N x N kernel): split K over workgroups so that the
+    // 256 compute units (two workgroups each) have work; partial tiles go to a stream-ordered scratch buffer and are
+    // summed in a fixed order.  Measured (serving mode, 128 queries, N = 10800): see DESIGN.md section 7.
+    int ksplit = 1;
+    if (kmode != 2 && tm * tn <= 256 && k / DBK >= 128 && g_debug[5] != 9) {
+        ksplit = (int)(512 / (tm * tn));
+        if (ksplit > 8) ksplit = 8;
+        while (ksplit > 1 && (k / DBK) / ksplit < 32) --ksplit;
+    }
+    if (ksplit <= 1) {
+        hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
+                           a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, 1, nullptr, 0);
+        NNGP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    const int64_t part_stride = m * ldc;
+    double* part = nullptr;
+    NNGP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&part), sizeof(double) * part_stride * ksplit, s));
+    if (kmode == 1)  // tiles whose k range is empty or short leave (parts of) their slots unwritten
+        NNGP_HIP_CHECK(hipMemsetAsync(part, 0, sizeof(double) * part_stride * ksplit, s));
+    hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn * ksplit)), dim3(256), 0, s, c, ldc, cin ? cin : c,
+                       ldcin ? ldcin : ldc, a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, ksplit, part,
+                       part_stride);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, s, c, ldc, cin ? cin : c,
+                       ldcin ? ldcin : ldc, part, part_stride, ksplit, n, alpha, beta);
     NNGP_HIP_CHECK(hipGetLastError());
+    NNGP_HIP_CHECK(hipFreeAsync(part, s));
     return 0;
 }
 

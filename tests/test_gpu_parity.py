@@ -254,6 +254,19 @@ def test_gemm_f64_mfma():
     c = torch.randn((384, 256), dtype=torch.float64, device=G.dev()); ref = 0.5 * c + 2.0 * a @ b.T
     G.gemm_nt_f64(c, c, a, b, 2.0, 0.5)
     assert (c - ref).abs().max().item() < 1e-11
+    # few tiles and a long K: the split-K path (partial tiles + fixed-order reduction) -- exact on integers, in place,
+    # and the same bits on every run
+    m, n, k = 128, 384, 4096 + 48
+    a = torch.randint(-8, 9, (m, k), device=G.dev()).double(); b = torch.randint(-8, 9, (n, k), device=G.dev()).double()
+    cin = torch.randint(-8, 9, (m, n), device=G.dev()).double()
+    c = cin.clone()
+    G.gemm_nt_f64(c, c, a, b, -1.0, 3.0)
+    assert torch.equal(c, 3.0 * cin - a @ b.T)
+    a = torch.randn((256, 8192), dtype=torch.float64, device=G.dev()); b = torch.randn((640, 8192), dtype=torch.float64, device=G.dev())
+    c1 = torch.empty((256, 640), dtype=torch.float64, device=G.dev()); c2 = torch.empty_like(c1)
+    G.gemm_nt_f64(c1, None, a, b, 1.0, 0.0)
+    G.gemm_nt_f64(c2, None, a, b, 1.0, 0.0)
+    assert torch.equal(c1, c2) and (c1 - a @ b.T).abs().max().item() < 1e-10
 
 
 # ---------------------------------------------------------------------------- Cholesky / TRSM
