@@ -653,6 +653,8 @@ def test_random_sweep_against_the_float64_oracle(seed):
     model = GPModel(c["n"], c["d"], a.w_std, a.b_std, get=c["get"], diag_reg=c["diag_reg"],
                     diag_reg_absolute_scale=c["absolute"]).fit(x, y)
     info = model.info()
+    if os.environ.get("NNGP_SWEEP_SERVING"):  # exploration: the same cases through the explicit-inverse serving mode
+        model.prepare_serving()
     mean, var = model.predict(xt, cov="diag")
     cov_iters, shift = model.cov_iters(), model.factor_shift() / info["reg"]
     _, cov = model.predict(xt[:64], cov="full")
@@ -684,8 +686,8 @@ def test_random_sweep_against_the_float64_oracle(seed):
         pass
     model.close()
     assert row["clamped"] == 0 and row["reg_rel"] < 1e-8, row
-    if c["get"] == "nngp" and row["cg_iters"] >= 8:  # weak preconditioner: the rows must have gone on by CG
-        assert cov_iters > 0 and row["var_max_rel"] < 1e-6, row
+    if c["get"] == "nngp" and row["cg_iters"] >= 8 and not os.environ.get("NNGP_SWEEP_SERVING"):
+        assert cov_iters > 0 and row["var_max_rel"] < 1e-6, row  # weak preconditioner: the rows must have gone on by CG
     # small regularisers (1e-4 relative, or absolute on a large-trace kernel) raise cond(K + reg I): alpha itself is
     # then determined to ~cond * eps64 only, the mean stays at the gate
     assert row["mean_rel_l2"] < 1e-6 and row["mean_elem"] < 1e-5, row
