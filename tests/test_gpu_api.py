@@ -179,7 +179,7 @@ def test_append_rows_matches_full_refit(n0, b, ncap):
     inc.close()
 
 
-@pytest.mark.parametrize("get,n,d,reg", [("nngp", 2500, 20, 1e-3), ("ntk", 1300, 16, 1e-3), ("nngp", 2706, 3, 1e-4)])
+@pytest.mark.parametrize("get,n,d,reg", [("nngp", 2500, 20, 1e-3), ("ntk", 1300, 16, 1e-3), ("nngp", 2706, 3, 1e-4), ("nngp", 130, 5, 1e-3)])
 def test_serving_mode_matches_the_solve_path(get, n, d, reg):
     """nngp_model_prepare_serving: predictions through the explicit float64 inverse against the solve path at level 3
     (diag, full, x_test=None), on a well-conditioned fit of each kernel and on the ill-conditioned NNGP fit of the sweep;
