@@ -125,6 +125,7 @@ struct nngp_model {
     hipStream_t solve_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
     bool solve_pending = false;
+    int solve_ahead = 0;  // > 0: the first `solve_ahead` CG iterations are already in flight on solve_stream (ny == 1)
     int pend_max_iters = 60;
     double pend_tol = 1e-10;
 
@@ -216,6 +217,15 @@ int ensure_full_cov_capacity(nngp_model* m, int64_t mt) {
         NNGP_TRY(dev_alloc(&m->covp64, mp * mp));
         m->full_cap = mt;
     }
+    return 0;
+}
+
+// A CG that was started ahead (nngp_model_solve) reads y, K, the factor and the CG workspace: anything that is about to
+// overwrite those waits for it and drops it.
+int drop_pending_solve(nngp_model* m) {
+    if (m->solve_pending && m->solve_ahead > 0) NNGP_HIP_CHECK(hipStreamSynchronize(m->solve_stream));
+    m->solve_pending = false;
+    m->solve_ahead = 0;
     return 0;
 }
 
@@ -472,14 +482,14 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     A(dev_alloc(&m->pcg.r, np)); A(dev_alloc(&m->pcg.z, np)); A(dev_alloc(&m->pcg.p, np)); A(dev_alloc(&m->pcg.q, np));
     A(dev_alloc(&m->pcg.xcol, np)); A(dev_alloc(&m->pcg.bcol, np));
     A(dev_alloc(&m->pcg.f32a, np)); A(dev_alloc(&m->pcg.f32b, np)); A(dev_alloc(&m->pcg.f32c, np));
-    A(dev_alloc(&m->pcg.scal, 8));
+    A(dev_alloc(&m->pcg.scal, 32));
     {
         const int64_t bs_cap = triinv_block(np);
         const int64_t nblk = (np + bs_cap - 1) / bs_cap;
         A(dev_alloc(&m->tri.tinv, nblk * bs_cap * bs_cap)); A(dev_alloc(&m->tri.xinv, nblk * bs_cap * bs_cap));
         A(dev_alloc(&m->tri.partial, (bs_cap / TB) * np)); A(dev_alloc(&m->tri.tmp, bs_cap));
     }
-    if (rc == 0 && hipHostMalloc(reinterpret_cast<void**>(&m->pcg.host_scal), sizeof(double) * 8) != hipSuccess) {
+    if (rc == 0 && hipHostMalloc(reinterpret_cast<void**>(&m->pcg.host_scal), sizeof(double) * 32) != hipSuccess) {
         set_error("model_create: hipHostMalloc failed");
         rc = -1;
     }
@@ -522,6 +532,7 @@ int nngp_model_set_train(nngp_model* m, const double* x, const double* y, int64_
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && x != nullptr && y != nullptr, "set_train: NULL argument");
     NNGP_REQUIRE(n > 0 && n <= m->n_cap, "set_train: n=%lld outside (0, n_cap=%lld]", (long long)n, (long long)m->n_cap);
+    NNGP_TRY(drop_pending_solve(m));
     m->n = n;
     m->np = round_up(n, TB);
     m->built = m->factored = m->solved = false;
@@ -548,6 +559,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->have_train, "build_rows: call set_train first");
     NNGP_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= m->n, "build_rows: bad row range");
+    NNGP_TRY(drop_pending_solve(m));
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
     a.n1 = m->n; a.n2 = m->n; a.d = m->d;
@@ -573,6 +585,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
 int nngp_model_factor_begin(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
+    NNGP_TRY(drop_pending_solve(m));
     // a32 = float32(K) + reg I on the lower tiles; if the build already wrote it, only the last (partial + padding)
     // block row is left
     NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, m->n, m->np, m->reg_fac, m->reg_fac + m->trace_mean, s,
@@ -673,6 +686,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
                  (long long)m->n_cap);
     const int64_t n0 = m->n, n1 = n0 + b, np0 = m->np, np1 = round_up(n1, TB), r0 = (n0 / TB) * TB, rows = np1 - r0;
     NNGP_REQUIRE(r0 > 0, "append: the fitted model must have at least 128 rows");
+    NNGP_TRY(drop_pending_solve(m));
     NNGP_TRY(ensure_predict_capacity(m, rows, false));  // b32 / trsm_tmp workspace of the blocked solve
     // 1. data, diagonal, regulariser
     NNGP_HIP_CHECK(hipMemcpyAsync(m->x + n0 * m->d, x_new, sizeof(double) * b * m->d, hipMemcpyDeviceToDevice, s));
@@ -731,23 +745,33 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     return 0;
 }
 
-// Runs the deferred CG solve (see nngp_model: solve_stream).  `user`: the stream whose later work needs alpha.
+// Runs the deferred CG solve for alpha (see nngp_model: solve_stream).  `user`: the stream whose later work needs alpha.
+constexpr int kSolveAhead = 6;  // run-ahead experiment (nngp_model_solve): the bench sizes converge in 5 / 6 iterations
+
 static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user) {
     if (!m->solve_pending) return 0;
     m->solve_pending = false;
     hipStream_t s = m->solve_stream;
-    NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_ready, 0));
     m->iters = 0;
     m->relres = 0.0;
-    for (int c = 0; c < m->ny; ++c) {
-        NNGP_TRY(launch_strided_copy_f64(m->y + c, m->ny, m->pcg.bcol, 1, m->n, s));
-        int it = 0;
-        double rr = 0.0;
-        NNGP_TRY(pcg_solve(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
-                           m->pcg, m->pend_max_iters, m->pend_tol, &it, &rr, s));
-        NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
-        if (it > m->iters) m->iters = it;
-        if (rr > m->relres) m->relres = rr;
+    if (m->solve_ahead > 0) {
+        const int ahead = m->solve_ahead;
+        m->solve_ahead = 0;
+        NNGP_TRY(pcg_finish(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.xcol, m->pcg, ahead,
+                            m->pend_max_iters, m->pend_tol, &m->iters, &m->relres, s));
+        NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha, m->ny, m->n, s));
+    } else {
+        NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_ready, 0));
+        for (int c = 0; c < m->ny; ++c) {
+            NNGP_TRY(launch_strided_copy_f64(m->y + c, m->ny, m->pcg.bcol, 1, m->n, s));
+            int it = 0;
+            double rr = 0.0;
+            NNGP_TRY(pcg_solve(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
+                               m->pcg, m->pend_max_iters, m->pend_tol, &it, &rr, s));
+            NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
+            if (it > m->iters) m->iters = it;
+            if (rr > m->relres) m->relres = rr;
+        }
     }
     NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
     if (order_user) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
@@ -758,6 +782,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user) {
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->factored, "solve: factor first");
+    NNGP_TRY(drop_pending_solve(m));
     // default: 60 iterations; a factor with a raised shift preconditions worse by ~ sqrt(reg_fac / reg)
     const double weak = (m->reg > 0.0 && m->reg_fac > m->reg) ? sqrt(m->reg_fac / m->reg) : 1.0;
     m->pend_max_iters = max_iters > 0 ? max_iters : (int)fmin(2000.0, 60.0 * weak);
@@ -766,6 +791,18 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
     m->solve_pending = true;
     m->solved = true;
     if (g_debug[7] == 3) return run_pending_solve(m, s, true);  // timing experiment: solve now, in stream order
+    // (measured and dropped: starting the first six CG iterations here, on the solve stream, without waiting on the host
+    // (pcg_begin / pcg_finish) -- the CG then runs beside the posterior's float32 solves instead of under its float64
+    // GEMMs, and the two latency-bound kernel chains slow each other down by what the overlap gains: N = 32768: 155.8 vs
+    // 152.5 ms per step, N = 8192: 16.0 vs 15.3, N = 65536: 716 vs 706.  Debug key 0 = 64 enables it for timing.)
+    if (m->ny == 1 && g_debug[0] == 64) {
+        const int ahead = m->pend_max_iters < kSolveAhead ? m->pend_max_iters : kSolveAhead;
+        NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_ready, 0));
+        NNGP_TRY(launch_strided_copy_f64(m->y, 1, m->pcg.bcol, 1, m->n, m->solve_stream));
+        NNGP_TRY(pcg_begin(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol, m->pcg, ahead,
+                           m->solve_stream));
+        m->solve_ahead = ahead;
+    }
     return 0;
 }
 

@@ -350,51 +350,92 @@ int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, co
 }
 
 // Preconditioned CG for (K + reg I) x = b in float64; M^-1 = (L L^T)^-1 with the float32 factor.
-int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
-              const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
-              double tol, int* iters_out, double* relres_out, hipStream_t s) {
-    auto precond = [&](const double* rin, double* zout) -> int {
-        hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks256(np)), dim3(256), 0, s, rin, w.f32a, n, np);
-        NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, s));
-        NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32a, s));
-        hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32a, zout, n);
-        return 0;
-    };
-    // x = 0, r = b
+// The scalars (rz, pAp, alpha, beta) live on the device; the host only reads |r|^2 to decide when to stop.  Two phases:
+//   pcg_begin  enqueues x = 0, r = b and `ahead` iterations WITHOUT waiting (|b|^2 and the |r|^2 of every iteration go to
+//              w.scal[8...]); iterating past convergence is harmless (the update kernels take alpha = beta = 0 when their
+//              denominators vanish), so the solve can run on its own stream from the moment the factor is ready;
+//   pcg_finish waits, reads the history, and continues one iteration at a time if `ahead` were not enough.
+namespace {
+constexpr int kPcgHist = 8;       // w.scal[8] = |b|^2, w.scal[9 + it] = |r|^2 after iteration it
+constexpr int kPcgMaxAhead = 22;  // w.scal has 32 slots
+
+int pcg_iteration(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
+                  int64_t np, double* xcol, PcgWork& w, int it, double* rr_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks256(np)), dim3(256), 0, s, w.r, w.f32a, n, np);
+    NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, s));
+    NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32a, s));
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32a, w.z, n);
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.z, n, w.scal + 2);  // rz_new
+    hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks256(n)), dim3(256), 0, s, w.p, w.z, n, w.scal, it == 0);
+    hipLaunchKernelGGL(k_scal_shift, dim3(1), dim3(1), 0, s, w.scal);  // rz = rz_new
+    NNGP_TRY(launch_gemv_f64(k64, ld, n, n, w.p, 1, w.q, 1, reg, s));
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.p, w.q, n, w.scal + 1);  // pAp
+    hipLaunchKernelGGL(k_pcg_update_xr, dim3(blocks256(n)), dim3(256), 0, s, xcol, w.r, w.p, w.q, n, w.scal);
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.r, n, rr_out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+int pcg_begin(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
+              int64_t np, const double* bcol, double* xcol, PcgWork& w, int ahead, hipStream_t s) {
+    NNGP_REQUIRE(ahead >= 0 && ahead <= kPcgMaxAhead, "pcg_begin: at most %d iterations ahead", kPcgMaxAhead);
     NNGP_HIP_CHECK(hipMemsetAsync(xcol, 0, sizeof(double) * n, s));
     NNGP_HIP_CHECK(hipMemcpyAsync(w.r, bcol, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, bcol, bcol, n, w.scal + 4);
-    NNGP_HIP_CHECK(hipMemcpyAsync(w.host_scal + 4, w.scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, bcol, bcol, n, w.scal + kPcgHist);
+    for (int it = 0; it < ahead; ++it)
+        NNGP_TRY(pcg_iteration(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, it, w.scal + kPcgHist + 1 + it, s));
+    NNGP_HIP_CHECK(hipMemcpyAsync(w.host_scal + kPcgHist, w.scal + kPcgHist, sizeof(double) * (1 + ahead), hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+int pcg_finish(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
+               int64_t np, double* xcol, PcgWork& w, int ahead, int max_iters, double tol, int* iters_out,
+               double* relres_out, hipStream_t s) {
     NNGP_HIP_CHECK(hipStreamSynchronize(s));
-    const double bnorm2 = w.host_scal[4];
+    const double bnorm2 = w.host_scal[kPcgHist];
     int iters = 0;
     double relres = 0.0;
     if (bnorm2 > 0.0) {
         relres = 1.0;
-        for (int it = 0; it < max_iters; ++it) {
-            NNGP_TRY(precond(w.r, w.z));
-            hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.z, n, w.scal + 2);  // rz_new
-            hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks256(n)), dim3(256), 0, s, w.p, w.z, n, w.scal, it == 0);
-            hipLaunchKernelGGL(k_scal_shift, dim3(1), dim3(1), 0, s, w.scal);  // rz = rz_new
-            NNGP_TRY(launch_gemv_f64(k64, ld, n, n, w.p, 1, w.q, 1, reg, s));
-            hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.p, w.q, n, w.scal + 1);  // pAp
-            hipLaunchKernelGGL(k_pcg_update_xr, dim3(blocks256(n)), dim3(256), 0, s, xcol, w.r, w.p, w.q, n, w.scal);
-            hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.r, n, w.scal + 3);
+        bool done = false;
+        for (int it = 0; it < ahead; ++it) {  // the iterations that ran ahead: where did the residual first meet tol?
+            const double rel = sqrt(w.host_scal[kPcgHist + 1 + it] / bnorm2);
+            if (!(rel == rel)) {  // NaN: the preconditioner is unusable
+                set_error("pcg_solve: residual became NaN at iteration %d", it + 1);
+                return -3;
+            }
+            if (!done) {
+                iters = it + 1;
+                relres = rel;
+                if (rel <= tol) done = true;
+            } else if (rel < relres) {
+                relres = rel;  // the extra iterations only polish
+            }
+        }
+        for (int it = ahead; it < max_iters && !done; ++it) {
+            NNGP_TRY(pcg_iteration(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, it, w.scal + 3, s));
             NNGP_HIP_CHECK(hipMemcpyAsync(w.host_scal + 3, w.scal + 3, sizeof(double), hipMemcpyDeviceToHost, s));
             NNGP_HIP_CHECK(hipStreamSynchronize(s));
             iters = it + 1;
             relres = sqrt(w.host_scal[3] / bnorm2);
-            if (!(relres == relres)) {  // NaN: the preconditioner is unusable
+            if (!(relres == relres)) {
                 set_error("pcg_solve: residual became NaN at iteration %d", iters);
                 return -3;
             }
-            if (relres <= tol) break;
+            if (relres <= tol) done = true;
         }
     }
-    NNGP_HIP_CHECK(hipGetLastError());
     if (iters_out) *iters_out = iters;
     if (relres_out) *relres_out = relres;
     return 0;
+}
+
+int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
+              const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
+              double tol, int* iters_out, double* relres_out, hipStream_t s) {
+    NNGP_TRY(pcg_begin(k64, ld, n, reg, l32, ld32, ti, np, bcol, xcol, w, 0, s));
+    return pcg_finish(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, 0, max_iters, tol, iters_out, relres_out, s);
 }
 
 }  // namespace nngp
