@@ -172,8 +172,8 @@ int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t
 int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
                        float* tmp, const SplitWork& sw, hipStream_t s);
 // in-place solves L x = b / L^T x = b on a float32 vector of length np
-int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);
-int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s);
+int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, float* x, hipStream_t s);
+int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, float* x, hipStream_t s);
 int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, const double* x, int64_t incx,
                     double* y, int64_t incy, double diag_add, hipStream_t s);
 struct PcgWork {

@@ -301,37 +301,41 @@ int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_
     return 0;
 }
 
-// Solves L x = b in place (b, length np, float32).  Block J: x_J = X_J b_J, then b[below] -= L[below, J] x_J.
-int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s) {
+// Solves L x = b (float32, length np).  Block J: x_J = X_J b_J, then b[below] -= L[below, J] x_J.  b is consumed (its rows
+// below the current block are updated in place); the solution goes to x, a different buffer -- writing x_J over b_J would
+// need a staging copy per block, one more launch in a chain whose cost is its launch count.
+// (Measured and dropped: fusing the backward sweep's partial-sum and reduction kernels with a last-arriver counter --
+// the agent-scope release each workgroup then needs writes back its XCD's L2: CG alone 24.7 instead of 15.0 ms.)
+int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, float* x, hipStream_t s) {
+    NNGP_REQUIRE(b != x, "trsv_forward: b and x must be different buffers");
     const int64_t bs = ti.bs;
     for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
         const int64_t sz = (np - o < bs) ? np - o : bs;
         hipLaunchKernelGGL(k_gemv_n_f32, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, s, ti.xinv + j * bs * bs, bs, sz, sz,
-                           b + o, ti.tmp, 0);
-        NNGP_HIP_CHECK(hipMemcpyAsync(b + o, ti.tmp, sizeof(float) * sz, hipMemcpyDeviceToDevice, s));
+                           b + o, x + o, 0);
         const int64_t below = np - o - sz;
         if (below > 0)
             hipLaunchKernelGGL(k_gemv_n_f32, dim3((unsigned)((below + 3) / 4)), dim3(256), 0, s, l + (o + sz) * ld + o, ld,
-                               below, sz, b + o, b + o + sz, 1);
+                               below, sz, x + o, b + o + sz, 1);
     }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// Solves L^T x = b in place.  Block J (last to first): x_J = X_J^T b_J = T_J b_J, then b[:o] -= L[J rows, :o]^T x_J.
-int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, hipStream_t s) {
+// Solves L^T x = b.  Block J (last to first): x_J = X_J^T b_J = T_J b_J, then b[:o] -= L[J rows, :o]^T x_J.  b is consumed.
+int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, float* x, hipStream_t s) {
+    NNGP_REQUIRE(b != x, "trsv_backward: b and x must be different buffers");
     const int64_t bs = ti.bs;
     const int64_t nblk = (np + bs - 1) / bs;
     for (int64_t j = nblk - 1; j >= 0; --j) {
         const int64_t o = j * bs;
         const int64_t sz = (np - o < bs) ? np - o : bs;
         hipLaunchKernelGGL(k_gemv_n_f32, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, s, ti.tinv + j * bs * bs, bs, sz, sz,
-                           b + o, ti.tmp, 0);
-        NNGP_HIP_CHECK(hipMemcpyAsync(b + o, ti.tmp, sizeof(float) * sz, hipMemcpyDeviceToDevice, s));
+                           b + o, x + o, 0);
         if (o > 0) {
             const int nchunk = (int)(sz / 128);
             hipLaunchKernelGGL(k_gemv_t_partial_f32, dim3((unsigned)((o + 255) / 256), (unsigned)nchunk), dim3(256), 0, s,
-                               l + o * ld, ld, o, b + o, ti.partial, np);
+                               l + o * ld, ld, o, x + o, ti.partial, np);
             hipLaunchKernelGGL(k_sub_partials_f32, dim3((unsigned)((o + 255) / 256)), dim3(256), 0, s, b, ti.partial, np,
                                nchunk, o);
         }
@@ -362,9 +366,9 @@ constexpr int kPcgMaxAhead = 22;  // w.scal has 32 slots
 int pcg_iteration(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
                   int64_t np, double* xcol, PcgWork& w, int it, double* rr_out, hipStream_t s) {
     hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks256(np)), dim3(256), 0, s, w.r, w.f32a, n, np);
-    NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, s));
-    NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32a, s));
-    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32a, w.z, n);
+    NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, w.f32b, s));
+    NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32b, w.f32c, s));
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32c, w.z, n);
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.z, n, w.scal + 2);  // rz_new
     hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks256(n)), dim3(256), 0, s, w.p, w.z, n, w.scal, it == 0);
     hipLaunchKernelGGL(k_scal_shift, dim3(1), dim3(1), 0, s, w.scal);  // rz = rz_new
