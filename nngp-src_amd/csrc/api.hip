@@ -794,7 +794,8 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
     // (measured and dropped: starting the first six CG iterations here, on the solve stream, without waiting on the host
     // (pcg_begin / pcg_finish) -- the CG then runs beside the posterior's float32 solves instead of under its float64
     // GEMMs, and the two latency-bound kernel chains slow each other down by what the overlap gains: N = 32768: 155.8 vs
-    // 152.5 ms per step, N = 8192: 16.0 vs 15.3, N = 65536: 716 vs 706.  Debug key 0 = 64 enables it for timing.)
+    // 152.5 ms per step, N = 8192: 16.0 vs 15.3, N = 65536: 716 vs 706; the same with the solve stream at normal priority.
+    // Debug key 0 = 64 enables it for timing.)
     if (m->ny == 1 && g_debug[0] == 64) {
         const int ahead = m->pend_max_iters < kSolveAhead ? m->pend_max_iters : kSolveAhead;
         NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_ready, 0));
