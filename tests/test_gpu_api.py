@@ -216,3 +216,60 @@ def test_serving_mode_matches_the_solve_path(get, n, d, reg):
     _, var3 = ref.predict(xt, cov="diag")
     np.testing.assert_allclose(var2, var3, rtol=1e-5, atol=1e-9 * np.abs(var3).max())
     model.close(); ref.close()
+
+
+def test_c_abi_error_codes_instead_of_crashes():
+    """Stages called out of order, NULL outputs, capacities exceeded: every entry point must return a negative code and
+    leave a message in nngp_last_error -- never touch the GPU with bad arguments (include/nngp_hip.h: error behaviour)."""
+    import ctypes
+    from nngp_src_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    arch = _lib.make_arch([1.0, 1.0], [0.0, 0.0])
+    h = ctypes.c_void_p()
+
+    def failed(rc, needle):
+        msg = (lib.nngp_last_error() or b"").decode()
+        return rc < 0 and needle in msg, (rc, msg)
+
+    assert failed(lib.nngp_model_create(ctypes.byref(h), 0, 0, 4, 1, ctypes.byref(arch), _lib.GET_NNGP, 1e-3, 0), "bad sizes")[0]
+    assert failed(lib.nngp_model_create(ctypes.byref(h), 300, 0, 4, 1, ctypes.byref(arch), 7, 1e-3, 0), "get must be")[0]
+    assert lib.nngp_model_create(ctypes.byref(h), 300, 16, 4, 1, ctypes.byref(arch), _lib.GET_NNGP, 1e-3, 0) == 0
+    x = torch.rand((300, 4), dtype=torch.float64, device=dev) * 1000
+    y = torch.rand((300, 1), dtype=torch.float64, device=dev)
+    out = torch.empty((16, 1), dtype=torch.float64, device=dev)
+    var = torch.empty((16,), dtype=torch.float64, device=dev)
+    s = _lib.stream_ptr()
+    p = _lib.ptr
+    for call, needle in [
+        (lambda: lib.nngp_model_predict(h, p(x[:16]), 16, 1, p(out), p(var), s), "fit the model first"),
+        (lambda: lib.nngp_model_build_rows(h, 0, 10, s), "set_train first"),
+        (lambda: lib.nngp_model_factor(h, s), "build the kernel rows first"),
+        (lambda: lib.nngp_model_solve(h, 0, 0.0, s), "factor first"),
+        (lambda: lib.nngp_model_append(h, p(x[:4]), p(y[:4]), 4, s), "fit the model first"),
+        (lambda: lib.nngp_model_prepare_serving(h, s), "fit the model first"),
+        (lambda: lib.nngp_model_set_train(h, p(x), p(y), 301, s), "outside"),
+        (lambda: lib.nngp_model_set_train(h, None, p(y), 300, s), "NULL"),
+        (lambda: lib.nngp_model_set_refine(h, 99), "level"),
+    ]:
+        ok, info = failed(call(), needle)
+        assert ok, info
+    assert lib.nngp_model_fit(h, p(x[:280]), p(y[:280]), 280, s) == 0
+    for call, needle in [
+        (lambda: lib.nngp_model_predict(h, p(x[:16]), 16, 5, p(out), p(var), s), "cov_mode"),
+        (lambda: lib.nngp_model_predict(h, p(x[:16]), 16, 1, p(out), None, s), "NULL output"),
+        (lambda: lib.nngp_model_predict(h, p(x[:16]), -1, 0, p(out), None, s), "negative"),
+        (lambda: lib.nngp_model_build_rows(h, 5, 281, s), "bad row range"),
+        (lambda: lib.nngp_model_append(h, p(x[280:]), p(y[280:]), 21, s), "exceed"),
+    ]:
+        ok, info = failed(call(), needle)
+        assert ok, info
+    # the handle still works after all that
+    assert lib.nngp_model_predict(h, p(x[:16]), 16, 1, p(out), p(var), s) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and (var > 0).all()
+    assert lib.nngp_model_append(h, p(x[280:]), p(y[280:]), 20, s) == 0 and lib.nngp_model_solve(h, 0, 0.0, s) == 0
+    assert lib.nngp_model_predict(h, p(x[:16]), 16, 1, p(out), p(var), s) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and (var > 0).all()
+    lib.nngp_model_destroy(h)
