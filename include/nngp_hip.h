@@ -103,7 +103,11 @@ int nngp_model_fit(nngp_model* m, const double* x, const double* y, int64_t n, v
  *               waits for the factorisation (one 4-byte read-back of the clamped-pivot count).
  *   solve     : alpha = (K + reg I)^-1 Y by CG on the float64 kernel, preconditioned by the
  *               float32 factor (max_iters <= 0 and tol <= 0 select the defaults 60 / 1e-10; 60 is scaled by
- *               sqrt(shift / reg) when the factor carries a raised shift).
+ *               sqrt(shift / reg) when the factor carries a raised shift).  With one output column, a predict that
+ *               also forms covariance rows Z ~ K_td (K + reg I)^-1 stops this CG at 1e-6 and corrects the mean through
+ *               them: mu = K_td a_k + Z r_k, exact up to (K_td A^-1 - Z) r_k, the product of two small errors (means
+ *               agree with the converged solve to ~1e-9).  nngp_model_alpha, nngp_model_info and mean-only predicts
+ *               take the solve up again where it stopped and run it to tol.
  *               The call records the request; the CG itself runs on the model's own high-priority stream when alpha
  *               is first needed -- nngp_model_alpha / _info (which then block for it), or inside nngp_model_predict
  *               after the covariance work has been enqueued, so that it overlaps it.                          */

@@ -125,6 +125,11 @@ struct nngp_model {
     hipStream_t solve_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
     bool solve_pending = false;
+    // Early stop (ny == 1): a predict that also forms the covariance rows Z ~ K_td (K + reg I)^-1 stops the CG at 1e-6 and
+    // corrects the mean through them: mu = K_td a_k + Z r_k (exact up to (K_td A^-1 - Z) r_k, the product of two small
+    // errors).  cg_partial: alpha holds a_k and the CG state in pcg is intact; anything that needs alpha itself resumes.
+    bool cg_partial = false;
+    int cg_iters_done = 0;
     int solve_ahead = 0;  // > 0: the first `solve_ahead` CG iterations are already in flight on solve_stream (ny == 1)
     int pend_max_iters = 60;
     double pend_tol = 1e-10;
@@ -226,6 +231,7 @@ int drop_pending_solve(nngp_model* m) {
     if (m->solve_pending && m->solve_ahead > 0) NNGP_HIP_CHECK(hipStreamSynchronize(m->solve_stream));
     m->solve_pending = false;
     m->solve_ahead = 0;
+    m->cg_partial = false;
     return 0;
 }
 
@@ -748,18 +754,51 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
 // Runs the deferred CG solve for alpha (see nngp_model: solve_stream).  `user`: the stream whose later work needs alpha.
 constexpr int kSolveAhead = 6;  // run-ahead experiment (nngp_model_solve): the bench sizes converge in 5 / 6 iterations
 
-static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user) {
-    if (!m->solve_pending) return 0;
-    m->solve_pending = false;
+constexpr double kPartialTol = 1e-6;
+
+// iterations the solve needs (or would need) to reach pend_tol, from the rate it converged at
+static void note_solve(nngp_model* m, int it, double rr) {
+    int est = it;
+    if (rr > m->pend_tol && rr > 0.0 && rr < 1.0 && it > 0) est = (int)ceil(it * log(m->pend_tol) / log(rr));
+    if (est > m->iters) m->iters = est;
+    if (rr > m->relres) m->relres = rr;
+}
+
+// allow_partial: the caller can correct the mean through the covariance rows, so the CG may stop at kPartialTol.
+static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, bool allow_partial = false) {
     hipStream_t s = m->solve_stream;
+    if (!m->solve_pending) {
+        if (!m->cg_partial || allow_partial) return 0;
+        // alpha itself is needed: take the stopped solve up again where it was
+        int it = 0;
+        double rr = 0.0;
+        NNGP_TRY(pcg_finish(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.xcol, m->pcg, m->cg_iters_done,
+                            m->pend_max_iters, m->pend_tol, &it, &rr, s, true));
+        NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha, m->ny, m->n, s));
+        m->cg_partial = false;
+        m->iters = 0;
+        m->relres = 0.0;
+        note_solve(m, it, rr);
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
+        if (order_user) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
+        else NNGP_HIP_CHECK(hipStreamSynchronize(s));
+        return 0;
+    }
+    m->solve_pending = false;
     m->iters = 0;
     m->relres = 0.0;
+    m->cg_partial = false;
+    const bool partial = allow_partial && m->ny == 1 && m->pend_tol < kPartialTol && g_debug[0] != 128;
+    const double tol = partial ? kPartialTol : m->pend_tol;
     if (m->solve_ahead > 0) {
         const int ahead = m->solve_ahead;
         m->solve_ahead = 0;
+        int it = 0;
+        double rr = 0.0;
         NNGP_TRY(pcg_finish(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.xcol, m->pcg, ahead,
-                            m->pend_max_iters, m->pend_tol, &m->iters, &m->relres, s));
+                            m->pend_max_iters, m->pend_tol, &it, &rr, s));
         NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha, m->ny, m->n, s));
+        note_solve(m, it, rr);
     } else {
         NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_ready, 0));
         for (int c = 0; c < m->ny; ++c) {
@@ -767,10 +806,13 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user) {
             int it = 0;
             double rr = 0.0;
             NNGP_TRY(pcg_solve(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol,
-                               m->pcg, m->pend_max_iters, m->pend_tol, &it, &rr, s));
+                               m->pcg, m->pend_max_iters, tol, &it, &rr, s));
             NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha + c, m->ny, m->n, s));
-            if (it > m->iters) m->iters = it;
-            if (rr > m->relres) m->relres = rr;
+            if (partial && rr > m->pend_tol) {
+                m->cg_partial = true;
+                m->cg_iters_done = it;
+            }
+            note_solve(m, it, rr);
         }
     }
     NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
@@ -931,6 +973,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // Levels >= 2 check afterwards whether the fixed number of correction sweeps was enough (cov_adaptive below):
     // 0 nothing to check, 1 NNGP diag, 2 NNGP full, 3 NTK.
     int check_kind = 0;
+    bool z_valid = false;  // z64 ends up holding the rows K_td (K + reg I)^-1 (to first order): the mean can be corrected through them
     const bool full = (cov_mode == NNGP_COV_FULL);
     const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
     auto ntk_finish = [&]() -> int {    // from z64 = Theta_td (Theta_dd + reg I)^-1; K_tt already in ktt64 (full)
@@ -1012,6 +1055,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             return launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, var_or_cov, -1.0, var_or_cov, s);
         }
         if (!full && serving && mt <= (np <= 16384 ? 32 : 16) && !m->serving_weak) {
+            z_valid = true;
             // a handful of queries against the explicit inverse: two passes over N x N float64 matrices (X, then K) per
             // group of 8 queries, both HBM-bound; var = K_tt - (2 z.k - z^T (K + reg I) z).  (Measured, ms per call,
             // streamed groups / 128-row MFMA GEMM -- N = 10800: 8 queries 0.62 / 3.06; N = 32768: 4.07 / 9.29.)
@@ -1028,6 +1072,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             // the symmetric K: W = 2 Z strict_lower_blocks(K) + Z diag_blocks(K) -- HALF the float64 product that the
             // full residual costs (kmode 1 / 2 of the float64 GEMM), then var = K_tt - z.(2 k - W - reg z)
             NNGP_TRY(solve_rows(level - 1, false));
+            z_valid = true;
             NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->k64, m->ld, mp, np, np, 2.0, 0.0, s, 1));
             NNGP_TRY(launch_gemm_nt_f64(m->r64, np, m->r64, np, m->z64, np, m->k64, m->ld, mp, np, np, 1.0, 1.0, s, 2));
             NNGP_TRY(launch_axpby_mat(m->r64, -1.0, m->z64, -m->reg, np, mp, np, s));
@@ -1040,6 +1085,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
                                        m->rows.live + 1, s);
         }
         NNGP_TRY(solve_rows(second_order ? level - 1 : 1, second_order));
+        z_valid = true;
         if (!full)
             return launch_rowdot_f64(m->z64, ktd, 1.0, second_order ? m->r64 : nullptr, np, mt, np, m->tt_diag, -1.0,
                                      var_or_cov, s);
@@ -1088,12 +1134,13 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     }
     NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine < 2 ? 2 : m->var_refine, false, s));  // no error cancellation: >= 2 sweeps
     ntk_cross = ktd_n;
+    z_valid = true;
     if (full) NNGP_TRY(build_ktt());
     if (m->var_refine >= 2) check_kind = 3;
     return ntk_finish();
     };
     if (cov_mode != NNGP_COV_NONE) NNGP_TRY(cov_part());
-    NNGP_TRY(run_pending_solve(m, s, true));
+    NNGP_TRY(run_pending_solve(m, s, true, z_valid));
     // Were the fixed sweeps enough?  Two signs that the float32 factor is a weak preconditioner: the alpha solve needed
     // many CG iterations, or a row's first-order term is too large for its second-order error to be small (k_rows_prepare).
     // Then the rows go on by preconditioned CG until each has converged, and the covariance is formed again.
@@ -1138,6 +1185,13 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     }
     for (int c = 0; c < m->ny; ++c)
         NNGP_TRY(launch_gemv_f64(ktd, np, mt, n, m->alpha + c, m->ny, mean + c, m->ny, 0.0, s));
+    if (m->cg_partial && z_valid) {
+        // the CG stopped at a_k with residual r_k = y - A a_k (still in the CG workspace):
+        //   K_td A^-1 y = K_td a_k + (K_td A^-1) r_k = K_td a_k + Z r_k + (K_td A^-1 - Z) r_k,
+        // and the last term is the product of two small errors (rows: <= 1e-3 relative; r_k: <= 1e-6 |y|)
+        NNGP_TRY(launch_gemv_f64(m->z64, np, mt, n, m->pcg.r, 1, m->rows.delta, 1, 0.0, s));
+        NNGP_TRY(launch_axpby_mat(mean, 1.0, m->rows.delta, 1.0, mt, 1, mt, s));
+    }
     return 0;
 }
 

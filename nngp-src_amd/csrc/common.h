@@ -14,7 +14,8 @@ constexpr int TB = 128;  // Cholesky / GEMM tile edge; all float32 device matric
 void set_error(const char* fmt, ...);
 // Timing-experiment switches (nngp_debug_set / NNGP_DEBUG="key=value,..." in bench.py); all zero in normal operation:
 //   0  bit mask: 1, 2, 4 leaf-kernel ablations (wrong results); 1, 2, 8 split-float16 GEMM ablations (no loads / no MFMA /
-//      no C traffic; wrong results); 64 = start the alpha CG ahead, without waiting on the host (nngp_model_solve)
+//      no C traffic; wrong results); 64 = start the alpha CG ahead, without waiting on the host (nngp_model_solve);
+//      128 = never stop the alpha CG early (no mean correction through the covariance rows)
 //   1  block-column width of the look-ahead Cholesky (default 1024)
 //   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA
 //   3  1 = slower leaf variant; 3 = kernel build with the float64-MFMA Gram product; 10 + n = first n block columns of the
@@ -186,7 +187,7 @@ int pcg_begin(const double* k64, int64_t ld, int64_t n, double reg, const float*
               int64_t np, const double* bcol, double* xcol, PcgWork& w, int ahead, hipStream_t s);
 int pcg_finish(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
                int64_t np, double* xcol, PcgWork& w, int ahead, int max_iters, double tol, int* iters_out,
-               double* relres_out, hipStream_t s);
+               double* relres_out, hipStream_t s, bool resume = false);
 int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
               const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
               double tol, int* iters_out, double* relres_out, hipStream_t s);

@@ -393,17 +393,18 @@ int pcg_begin(const double* k64, int64_t ld, int64_t n, double reg, const float*
     return 0;
 }
 
+// resume: the solve was stopped after `ahead` iterations at a looser tolerance (the CG state in w is intact): go on from there.
 int pcg_finish(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
                int64_t np, double* xcol, PcgWork& w, int ahead, int max_iters, double tol, int* iters_out,
-               double* relres_out, hipStream_t s) {
+               double* relres_out, hipStream_t s, bool resume) {
     NNGP_HIP_CHECK(hipStreamSynchronize(s));
     const double bnorm2 = w.host_scal[kPcgHist];
-    int iters = 0;
+    int iters = resume ? ahead : 0;
     double relres = 0.0;
     if (bnorm2 > 0.0) {
         relres = 1.0;
         bool done = false;
-        for (int it = 0; it < ahead; ++it) {  // the iterations that ran ahead: where did the residual first meet tol?
+        for (int it = 0; it < ahead && !resume; ++it) {  // the iterations that ran ahead: where did the residual first meet tol?
             const double rel = sqrt(w.host_scal[kPcgHist + 1 + it] / bnorm2);
             if (!(rel == rel)) {  // NaN: the preconditioner is unusable
                 set_error("pcg_solve: residual became NaN at iteration %d", it + 1);
@@ -439,7 +440,7 @@ int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float*
               const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
               double tol, int* iters_out, double* relres_out, hipStream_t s) {
     NNGP_TRY(pcg_begin(k64, ld, n, reg, l32, ld32, ti, np, bcol, xcol, w, 0, s));
-    return pcg_finish(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, 0, max_iters, tol, iters_out, relres_out, s);
+    return pcg_finish(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, 0, max_iters, tol, iters_out, relres_out, s, false);
 }
 
 }  // namespace nngp

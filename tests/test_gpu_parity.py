@@ -342,7 +342,7 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     assert l2 < 1e-6 and elem < 1e-6, (l2, elem, info)
     np.testing.assert_allclose(var, np.diag(cov_ref), rtol=1e-5, atol=1e-9 * np.abs(cov_ref).max())
     mean2, cov = model.predict(xt, cov="full")
-    assert np.array_equal(mean2, mean)
+    np.testing.assert_allclose(mean2, mean, rtol=1e-8, atol=1e-8 * np.abs(mean).max())  # corrected through different rows Z
     assert np.abs(cov - cov_ref).max() < 1e-6 * np.abs(np.diag(cov_ref)).max()
     assert np.array_equal(cov, cov.T)
     np.testing.assert_allclose(np.diag(cov), var, rtol=1e-9)
@@ -359,7 +359,7 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     assert np.abs(var32 - np.diag(cov_ref)).max() < 1e-4 * prior.max()
     assert np.abs(cov32 - cov_ref).max() < 1e-4 * prior.max()
     model.set_refine(2)
-    assert np.array_equal(model.predict(xt, cov=False), mean)
+    np.testing.assert_allclose(model.predict(xt, cov=False), mean, rtol=1e-8, atol=1e-8 * np.abs(mean).max())  # full CG vs early stop + correction
     # x_test=None: predictions on the training rows (estimator.py:37-40)
     mean_tr, var_tr = model.predict(None, cov="diag")
     mtr_ref, ctr_ref = post.predict(None, "nngp", True)
@@ -652,11 +652,12 @@ def test_random_sweep_against_the_float64_oracle(seed):
     a = o.make_arch(c["n_relu"], c["w"], c["b"])
     model = GPModel(c["n"], c["d"], a.w_std, a.b_std, get=c["get"], diag_reg=c["diag_reg"],
                     diag_reg_absolute_scale=c["absolute"]).fit(x, y)
-    info = model.info()
     if os.environ.get("NNGP_SWEEP_SERVING"):  # exploration: the same cases through the explicit-inverse serving mode
         model.prepare_serving()
-    mean, var = model.predict(xt, cov="diag")
-    cov_iters, shift = model.cov_iters(), model.factor_shift() / info["reg"]
+    mean, var = model.predict(xt, cov="diag")  # before info(): the alpha CG stops early, the mean is corrected through Z
+    cov_iters = model.cov_iters()
+    info = model.info()
+    shift = model.factor_shift() / info["reg"]
     _, cov = model.predict(xt[:64], cov="full")
     prior = o.diag_kernel(np.sum(xt * xt, axis=1) / c["d"], a)[0].max()  # var = prior - ...: resolution eps64 * prior
     assert np.abs(np.diag(cov) - var[:64]).max() <= 1e-5 * np.abs(var[:64]).max() + 1e-13 * prior
@@ -775,4 +776,31 @@ def test_float32_factor_breakdown_is_retried_with_a_larger_shift():
     l2, elem = G.mean_gate(mean, mean_ref)
     assert l2 < 1e-6 and elem < 1e-5, (l2, elem, info)
     np.testing.assert_allclose(var, var_ref.ravel(), rtol=1e-4)
+    model.close()
+
+
+def test_early_stopped_cg_mean_correction():
+    """With a covariance, predict stops the alpha CG at 1e-6 and corrects the mean through the covariance rows:
+    mu = K_td a_k + Z r_k.  The mean must match the float64 oracle as well as the fully converged solve does, info() and
+    alpha() must take the solve up again and deliver the converged alpha, and a later mean-only predict must agree."""
+    n, m, d = 3000, 100, 24
+    x, y = synth.synthetic_queries(n, d, seed=21)
+    xt, _ = synth.synthetic_queries(m, d, seed=22)
+    a = o.make_arch(2)
+    ref = c_oracle.fit(x, y, a.w_std, a.b_std)
+    mean_ref, var_ref = c_oracle.predict_nngp(ref, xt, 1)
+    model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3)
+    model.set_train(x, y); model.build_rows(0, n); model.factor(); model.solve()   # no info(): the solve stays deferred
+    mean, var = model.predict(xt, cov="diag")                                      # early stop + correction
+    l2, elem = G.mean_gate(mean, mean_ref)
+    assert l2 < 1e-9 and elem < 1e-8, (l2, elem)
+    np.testing.assert_allclose(var, var_ref.ravel(), rtol=1e-5)
+    mean_full, _ = model.predict(xt[:50], cov="full")                              # same state, other rows Z
+    assert G.mean_gate(mean_full, mean_ref[:50])[0] < 1e-9
+    info = model.info()                                                            # resumes the CG to its tolerance
+    assert info["rel_residual"] <= 1e-10 and 3 <= info["refine_iters"] <= 8, info
+    assert G.rel_l2(model.alpha().cpu().numpy(), ref["alpha"]) < 1e-8
+    mean_only = model.predict(xt, cov=False)
+    assert G.mean_gate(mean_only, mean_ref)[0] < 1e-9
+    np.testing.assert_allclose(mean_only, mean, rtol=1e-8, atol=1e-8 * np.abs(mean).max())
     model.close()
