@@ -754,6 +754,9 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
 // Runs the deferred CG solve for alpha (see nngp_model: solve_stream).  `user`: the stream whose later work needs alpha.
 constexpr int kSolveAhead = 6;  // run-ahead experiment (nngp_model_solve): the bench sizes converge in 5 / 6 iterations
 
+// Stopping tolerance of the early-stopped solve.  Measured at N = 32768 (ms per step / error of the corrected mean): 1e-6:
+// 150.0 / 8e-11, 1e-4: 147.5 / 4e-9, 1e-2: 145.9 / 2e-7.  1e-6 it is: the iteration count extrapolated from a solve stopped
+// at 1e-4 underestimates slowly converging fits (two of the sweep's 72 cases then missed the adaptive covariance).
 constexpr double kPartialTol = 1e-6;
 
 // iterations the solve needs (or would need) to reach pend_tol, from the rate it converged at
@@ -788,8 +791,8 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
     m->iters = 0;
     m->relres = 0.0;
     m->cg_partial = false;
-    const bool partial = allow_partial && m->ny == 1 && m->pend_tol < kPartialTol && g_debug[0] != 128;
-    const double tol = partial ? kPartialTol : m->pend_tol;
+    const bool partial = allow_partial && m->ny == 1 && m->pend_tol < 1e-3 && g_debug[0] != 128;
+    const double tol = partial ? ((g_debug[3] >= 41 && g_debug[3] <= 52) ? pow(10.0, -(double)(g_debug[3] - 40)) : kPartialTol) : m->pend_tol;
     if (m->solve_ahead > 0) {
         const int ahead = m->solve_ahead;
         m->solve_ahead = 0;

@@ -16,6 +16,7 @@ void set_error(const char* fmt, ...);
 //   0  bit mask: 1, 2, 4 leaf-kernel ablations (wrong results); 1, 2, 8 split-float16 GEMM ablations (no loads / no MFMA /
 //      no C traffic; wrong results); 64 = start the alpha CG ahead, without waiting on the host (nngp_model_solve);
 //      128 = never stop the alpha CG early (no mean correction through the covariance rows)
+//   3  (also) 40 + e = stopping tolerance 10^-e of the early-stopped alpha CG (scripts/partial_tol_study.py)
 //   1  block-column width of the look-ahead Cholesky (default 1024)
 //   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA
 //   3  1 = slower leaf variant; 3 = kernel build with the float64-MFMA Gram product; 10 + n = first n block columns of the
