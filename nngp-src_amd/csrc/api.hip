@@ -129,6 +129,7 @@ struct nngp_model {
     // corrects the mean through them: mu = K_td a_k + Z r_k (exact up to (K_td A^-1 - Z) r_k, the product of two small
     // errors).  cg_partial: alpha holds a_k and the CG state in pcg is intact; anything that needs alpha itself resumes.
     bool cg_partial = false;
+    bool have_alpha_event = false;  // ev_solved has been recorded at least once
     int cg_iters_done = 0;
     int solve_ahead = 0;  // > 0: the first `solve_ahead` CG iterations are already in flight on solve_stream (ny == 1)
     int pend_max_iters = 60;
@@ -771,7 +772,12 @@ static void note_solve(nngp_model* m, int it, double rr) {
 static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, bool allow_partial = false) {
     hipStream_t s = m->solve_stream;
     if (!m->solve_pending) {
-        if (!m->cg_partial || allow_partial) return 0;
+        if (!m->cg_partial || allow_partial) {
+            // alpha was written on the solve stream: a caller on another stream than the one that triggered the solve
+            // still has to be ordered behind it (free once the event has completed)
+            if (order_user && m->solved && m->have_alpha_event) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
+            return 0;
+        }
         // alpha itself is needed: take the stopped solve up again where it was
         int it = 0;
         double rr = 0.0;
@@ -783,6 +789,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
         m->relres = 0.0;
         note_solve(m, it, rr);
         NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
+    m->have_alpha_event = true;
         if (order_user) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
         else NNGP_HIP_CHECK(hipStreamSynchronize(s));
         return 0;
@@ -819,6 +826,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
         }
     }
     NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
+    m->have_alpha_event = true;
     if (order_user) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
     else NNGP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
