@@ -654,6 +654,8 @@ def test_random_sweep_against_the_float64_oracle(seed):
                     diag_reg_absolute_scale=c["absolute"]).fit(x, y)
     if os.environ.get("NNGP_SWEEP_SERVING"):  # exploration: the same cases through the explicit-inverse serving mode
         model.prepare_serving()
+    if os.environ.get("NNGP_SWEEP_LEVEL"):    # exploration: another covariance precision level
+        model.set_refine(int(os.environ["NNGP_SWEEP_LEVEL"]))
     mean, var = model.predict(xt, cov="diag")  # before info(): the alpha CG stops early, the mean is corrected through Z
     cov_iters = model.cov_iters()
     info = model.info()
