@@ -124,6 +124,8 @@ struct nngp_model {
     // HBM-bound CG (float64 GEMV + float32 TRSVs) overlaps the MFMA-bound covariance products.
     hipStream_t solve_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
+    hipEvent_t ev_predict = nullptr;  // end of the last predict on its stream: it reads alpha and the CG residual
+    bool have_predict_event = false;
     bool solve_pending = false;
     // Early stop (ny == 1): a predict that also forms the covariance rows Z ~ K_td (K + reg I)^-1 stops the CG at 1e-6 and
     // corrects the mean through them: mu = K_td a_k + Z r_k (exact up to (K_td A^-1 - Z) r_k, the product of two small
@@ -146,6 +148,7 @@ struct nngp_model {
         if (solve_stream) (void)hipStreamDestroy(solve_stream);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
+        if (ev_predict) (void)hipEventDestroy(ev_predict);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
@@ -505,7 +508,8 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
     if (rc == 0 && (hipStreamCreateWithPriority(&m->solve_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
                     hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&m->ev_solved, hipEventDisableTiming) != hipSuccess)) {
+                    hipEventCreateWithFlags(&m->ev_solved, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_predict, hipEventDisableTiming) != hipSuccess)) {
         set_error("model_create: could not create the solve stream");
         rc = -1;
     }
@@ -778,7 +782,9 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
             if (order_user && m->solved && m->have_alpha_event) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
             return 0;
         }
-        // alpha itself is needed: take the stopped solve up again where it was
+        // alpha itself is needed: take the stopped solve up again where it was (behind the last predict, whose mean
+        // correction may still be reading the residual this is about to update)
+        if (m->have_predict_event) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_predict, 0));
         int it = 0;
         double rr = 0.0;
         NNGP_TRY(pcg_finish(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.xcol, m->pcg, m->cg_iters_done,
@@ -789,7 +795,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
         m->relres = 0.0;
         note_solve(m, it, rr);
         NNGP_HIP_CHECK(hipEventRecord(m->ev_solved, s));
-    m->have_alpha_event = true;
+        m->have_alpha_event = true;
         if (order_user) NNGP_HIP_CHECK(hipStreamWaitEvent(user, m->ev_solved, 0));
         else NNGP_HIP_CHECK(hipStreamSynchronize(s));
         return 0;
@@ -1203,6 +1209,8 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(launch_gemv_f64(m->z64, np, mt, n, m->pcg.r, 1, m->rows.delta, 1, 0.0, s));
         NNGP_TRY(launch_axpby_mat(mean, 1.0, m->rows.delta, 1.0, mt, 1, mt, s));
     }
+    NNGP_HIP_CHECK(hipEventRecord(m->ev_predict, s));
+    m->have_predict_event = true;
     return 0;
 }
 
