@@ -18,7 +18,8 @@ void set_error(const char* fmt, ...);
 //      128 = never stop the alpha CG early (no mean correction through the covariance rows)
 //   3  (also) 40 + e = stopping tolerance 10^-e of the early-stopped alpha CG (scripts/partial_tol_study.py)
 //   1  block-column width of the look-ahead Cholesky (default 1024)
-//   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA
+//   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA; 3 = panel-solve product on the
+//      float32 MFMA (trailing updates stay on the float16 pipe)
 //   3  1 = slower leaf variant; 3 = kernel build with the float64-MFMA Gram product; 10 + n = first n block columns of the
 //      Cholesky on the float32 MFMA; 20 + c = float32 lead of 128 c columns in the first trailing update (default 256)
 //   4  compute units the persistent split-float16 grid leaves free (default 32 in the Cholesky); panel CUs of the CU-mask

@@ -372,6 +372,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_in, 0));
     int rc = 0;
     int k = 0;
+    bool panel_split_done = false;  // the panel solve already left the split copy of this block column's rows in place
     for (int64_t o = 0; o < n && rc == 0; o += nb, ++k) {
         const int64_t nbk = (n - o < nb) ? n - o : nb;
         const int64_t m = n - o - nbk;  // rows below this block column
@@ -394,7 +395,33 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         NNGP_HIP_CHECK(hipEventRecord(la->ev_col[k], la->update));
         // ... then the other panel rows and the rest of the trailing matrix, overlapped with the next diagonal block
         if (rc == 0 && m > nb2) {
-            rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
+            // The solve of the remaining panel rows, X = B L_kk^-T, splits as X1 = B1 L11^-T, B2 -= X1 L21^T, X2 = B2 L22^-T
+            // over the two 512-column halves; the product in the middle is half of its work.  From the second block column
+            // on it runs on the float16 pipe too: X1 is split straight into its place in this block column's planes (the
+            // trailing update needs it there anyway), L21 into the planes' unused rows of the diagonal block.  (Block
+            // column 0 stays on the float32 MFMA: same-sign data, see below.  Debug key 2 = 3: float32 product.)
+            const bool h3_panel = h3 && k > 0 && nbk == nb && nb == 1024 && m - nb2 >= 2048 && g_debug[2] != 3 &&
+                                  !(g_debug[3] >= 10 && g_debug[3] < 20 && k < g_debug[3] - 10);
+            panel_split_done = false;
+            if (h3_panel) {
+                const int64_t ldp = 4 * sw->k_cap, h = nbk / 2, mr = m - nb2;
+                char* pk = sw->planes + (int64_t)k * sw->col_stride;        // planes of block column k, global row 0
+                char* xrows = pk + (o + nbk + nb2) * ldp;                    // rows of the panel being solved
+                float* b = akk + (nbk + nb2) * ld;
+                rc = trsm_rlt_f32(b, ld, mr, akk, ld, dk, h, la->update);                                  // X1
+                if (rc == 0) rc = launch_split_rows(b, ld, mr, h, sw->scale, xrows, ldp, la->update);
+                if (rc == 0) rc = launch_split_rows(akk + h * ld, ld, h, h, sw->scale, pk + (o + h) * ldp, ldp, la->update);  // L21
+                if (rc == 0)
+                    rc = launch_gemm_nt_h3(b + h, ld, xrows, pk + (o + h) * ldp, ldp, mr, h, h, -1.0f / (sw->scale * sw->scale), 1.0f,
+                                           false, 0, sw->counters, g_debug[4] > 0 ? g_debug[4] : 32, la->update);
+                if (rc == 0) rc = trsm_rlt_f32(b + h, ld, mr, akk + h * ld + h, ld, dk + (h / TB) * TB * TB, h, la->update);  // X2
+                if (rc == 0) rc = launch_split_rows(b + h, ld, mr, h, sw->scale, xrows + h * 4, ldp, la->update);
+                if (rc == 0)  // the rows solved first (critical path) go into the planes as well
+                    rc = launch_split_rows(p, ld, nb2, nbk, sw->scale, pk + (o + nbk) * ldp, ldp, la->update);
+                panel_split_done = true;
+            } else {
+                rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
+            }
             // The leading columns of the factor are large and of one sign (K is a positive kernel); the float16 MFMA
             // accumulator truncates toward zero, which biases long same-sign sums (-2.6e-8 relative at K = 1024 on
             // positive data, nothing on mixed signs; float32 MFMA: 1e-10).  A coherent error of that size in the first
@@ -417,7 +444,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // solves of the posterior read it again)
                 const int64_t ldp = 4 * sw->k_cap;
                 char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
-                if (rc == 0) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
+                if (rc == 0 && !panel_split_done) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
                 if (rc == 0)  // columns [lead, nbk) of the panel (K blocks are walked from the high end down)
                     rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp + lead * 4, planes + lead * 4, ldp, m - nb2, m,
                                            nbk - lead, -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, sw->counters, reserve,
