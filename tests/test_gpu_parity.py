@@ -618,6 +618,20 @@ def test_edge_cases_small_and_degenerate():
     mref3, _ = o.Posterior(xd, y3, a, diag_reg=1e-3).predict(xt2, "nngp", True)
     assert mean3.shape == (30, 3) and G.mean_gate(mean3, mref3)[0] < 1e-6
     np.testing.assert_allclose(var3, var, rtol=1e-9)
+    # all-zero queries (|x| = 0: the arc-cosine map's 0/0 corner), orthogonal and opposite queries (theta = pi/2, pi),
+    # in the training set and in the test set; with and without biases
+    for b_std in (0.0, 0.2):
+        az = o.make_arch(2, 1.1, b_std)
+        xz = np.vstack([x[:100], np.zeros((2, 20)), -x[:3], np.eye(20)[:4] * 7.0])
+        yz = np.vstack([y[:100], [[0.0], [0.1]], y[:3] + 1.0, [[1.0], [2.0], [3.0], [4.0]]])
+        mz = GPModel(len(xz), 20, az.w_std, az.b_std, diag_reg=1e-3).fit(xz, yz)
+        xtz = np.vstack([np.zeros((1, 20)), -x[5:7], np.eye(20)[6:8] * 3.0, xt2[:5]])
+        mean, var = mz.predict(xtz, cov="diag")
+        mref, cref = o.Posterior(xz, yz, az, diag_reg=1e-3).predict(xtz, "nngp", True)
+        assert np.isfinite(mean).all() and np.isfinite(var).all()
+        assert G.mean_gate(mean, mref)[0] < 1e-6
+        np.testing.assert_allclose(var, np.diag(cref), rtol=1e-4, atol=1e-9 * np.abs(cref).max())
+        mz.close()
     # wrong shapes are rejected on the host
     with pytest.raises(ValueError):
         md.predict(np.zeros((3, 19)))
