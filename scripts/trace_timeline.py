@@ -5,10 +5,11 @@ rows = list(csv.DictReader(open(path)))
 for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-# last factorisation: from the last k_factor_input to the first k_set_identity_blocks after it
-fi = [i for i, r in enumerate(rows) if "k_factor_input" in r["Kernel_Name"]][-1]
+# last factorisation: from the kernel build (or k_factor_input, when the factor input is not fused into the build) before
+# the last k_set_identity_blocks (start of the 1024-block inverses) to that kernel
+end = [i for i, r in enumerate(rows) if "k_set_identity_blocks" in r["Kernel_Name"]][-1]
+fi = [i for i in range(end) if "k_factor_input" in rows[i]["Kernel_Name"] or "k_build" in rows[i]["Kernel_Name"]][-1]
 t0 = rows[fi]["e"]
-end = next(i for i in range(fi, len(rows)) if "k_set_identity_blocks" in rows[i]["Kernel_Name"])
 t1 = rows[end]["s"]
 reg = [r for r in rows[fi + 1:end]]
 print("cholesky region ms", (t1 - t0) / 1e6, "kernels", len(reg))
