@@ -115,11 +115,12 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    if os.environ.get("NNGP_DEBUG"):  # timing experiments only, e.g. NNGP_DEBUG="2=1" disables the look-ahead Cholesky
-        from nngp_src_amd import _lib
+    knobs = bool(os.environ.get("NNGP_DEBUG"))
+    if knobs:  # timing experiments only (scripts/gpu_ab.sh), e.g. NNGP_DEBUG="2=1" disables the look-ahead Cholesky: runs on
+        from nngp_src_amd import _lib  # libnngp_hip_knobs.so -- the product library has no such switches
         for kv in os.environ["NNGP_DEBUG"].split(","):
             k, v = kv.split("=")
-            _lib.load().nngp_debug_set(int(k), int(v))
+            _lib.load(knobs=True).nngp_debug_set(int(k), int(v))
     n, d, n_relu, get, m, join_block, desc = CONFIGS[args.config]
     x, y = synth.synthetic_queries(n, d, seed=0, join_block=join_block)
     xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
@@ -128,7 +129,9 @@ def main():
     xt_local = xtd[m0:m1].contiguous()
     w_std, b_std = [1.0] * (n_relu + 1), [0.0] * (n_relu + 1)
     n_cap = distributed.row_chunk(n, world) * world
-    model = GPModel(n_cap, d, w_std, b_std, get=get, diag_reg=1e-3, m_cap=max(m1 - m0, 1))
+    model = GPModel(n_cap, d, w_std, b_std, get=get, diag_reg=1e-3, m_cap=max(m1 - m0, 1), knobs=knobs)
+    if os.environ.get("NNGP_REFINE"):  # covariance precision level (default: the library's)
+        model.set_refine(int(os.environ["NNGP_REFINE"]))
     cov = "diag" if get == "nngp" else False
     shard = world > 1 and os.environ.get("NNGP_DIST_MODE", "replicate") == "shard"
 

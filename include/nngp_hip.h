@@ -57,9 +57,11 @@ typedef struct nngp_fit_info {
 typedef struct nngp_model nngp_model;
 
 int nngp_version(void);
-/* Timing-experiment switches used by scripts/microbench.py (ablations that produce WRONG results on purpose);
- * every key is 0 in normal operation.  Not part of the stable interface. */
+#ifdef NNGP_TIMING_KNOBS
+/* Timing-experiment switches (ablations, some of which produce WRONG results on purpose).  NOT in libnngp_hip.so:
+ * only libnngp_hip_knobs.so, built with -DNNGP_TIMING_KNOBS for scripts/ and the A/B tests, exports it. */
 int nngp_debug_set(int32_t key, int32_t value);
+#endif
 const char* nngp_last_error(void);
 
 /* ---- a1: kernel_fn(x1, x2, get) ---------------------------------------------------------------
@@ -184,6 +186,22 @@ int nngp_model_cov_iters(nngp_model* m);
  * NTK, whose covariance has no such formula).  Any later set_train / factor / append drops the inverse.
  * Cost: ~N/1024 covariance-sized solves. */
 int nngp_model_prepare_serving(nngp_model* m, void* stream);
+
+/* ---- e: multi-GPU row-block shard -- the nt.batch(kernel_fn, device_count=G) slot (train.py:166-168) -----------
+ * One process per GPU.  Rank g builds rows [g*chunk, (g+1)*chunk), chunk = ceil(n / world), with
+ * nngp_model_build_rows (or nngp_kernel_build's row range) and ONE in-place RCCL all-gather over xGMI completes K on
+ * every rank.  librccl is bound at run time (dlopen): the library loads and everything else works without it.
+ * Rendezvous is the caller's business: rank 0 calls nngp_comm_unique_id, ships the 128 bytes to the other ranks by
+ * any channel (torch.distributed / MPI / a file), every rank calls nngp_comm_create on its own device.
+ *   nngp_allgather_rows  k: [>= world*chunk, ld] device matrix of dtype NNGP_DTYPE_F32/F64, own row block already written;
+ *   nngp_bcast           panel broadcast of the block-cyclic Cholesky (nngp_model_factor_panel output) from `root`. */
+typedef struct nngp_comm nngp_comm;
+int nngp_comm_unique_id(void* id128 /* host, 128 bytes */);
+int nngp_comm_create(nngp_comm** out, const void* id128 /* host */, int32_t world, int32_t rank);
+int nngp_comm_destroy(nngp_comm* c);
+const char* nngp_comm_library(void); /* which librccl was bound ("" if none) */
+int nngp_allgather_rows(void* k, int64_t n, int64_t ld, int32_t dtype, nngp_comm* c, void* stream);
+int nngp_bcast(void* buf, int64_t count, int32_t dtype, int32_t root, nngp_comm* c, void* stream);
 
 /* ---- N2: native query-line encoder (host code; replaces the per-line Python of estimator/encoder.py:59-97,187-250
  * and QuerySampler.py:157-221) --------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnngp_hip.so")
+KNOBS_LIB_PATH = os.path.join(_HERE, "libnngp_hip_knobs.so")  # same sources + timing knobs; scripts/ and A/B tests only
 
 GET_NNGP, GET_NTK = 1, 2
 DTYPE_F32, DTYPE_F64 = 0, 1
@@ -20,13 +21,14 @@ MAX_DENSE = 16
 
 # every symbol include/nngp_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "nngp_version", "nngp_debug_set", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
+    "nngp_version", "nngp_last_error", "nngp_kernel_build", "nngp_kernel_diag", "nngp_model_create",
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_append", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_factor_shift", "nngp_model_prepare_serving", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
-    "nngp_encoder_encode",
+    "nngp_encoder_encode", "nngp_comm_unique_id", "nngp_comm_create", "nngp_comm_destroy", "nngp_comm_library",
+    "nngp_allgather_rows", "nngp_bcast",
 )
 
 
@@ -45,28 +47,35 @@ class NngpError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libnngp_hip.so (no GPU needed to load; compute calls need one)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(knobs: bool = False):
+    """Load libnngp_hip.so (no GPU needed to load; compute calls need one).
+
+    ``knobs=True`` loads libnngp_hip_knobs.so instead -- the same sources built with -DNNGP_TIMING_KNOBS, which adds
+    ``nngp_debug_set`` (ablations for scripts/ and the A/B tests; some produce wrong results on purpose).  The product
+    library has no such entry point.  NNGP_KNOBS=1 in the environment makes it the default (scripts/ only)."""
+    knobs = bool(knobs) or os.environ.get("NNGP_KNOBS", "0") == "1"
+    if knobs in _libs:
+        return _libs[knobs]
+    path = KNOBS_LIB_PATH if knobs else LIB_PATH
+    if not os.path.exists(path):
         raise NngpError(
-            "libnngp_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C nngp-src_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+            "%s is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nngp-src_amd/csrc`; there is no CPU fallback." % (os.path.basename(path), path))
     # torch first: its wheel carries its own libamdhip64 / libhsa-runtime64.  Loaded in that order the library's
     # DT_NEEDED entries resolve to the copies torch already mapped (same SONAME); the other way round the process ends
     # up with two HSA runtimes and the second one reports "no ROCm-capable device" (seen on the GPU box).
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
     archp = ctypes.POINTER(NngpArch)
     lib.nngp_version.restype = ctypes.c_int
     lib.nngp_last_error.restype = ctypes.c_char_p
-    lib.nngp_debug_set.argtypes = [i32, i32]
+    if knobs:
+        lib.nngp_debug_set.argtypes = [i32, i32]
+        lib.nngp_debug_set.restype = ctypes.c_int
     lib.nngp_kernel_build.argtypes = [vp, i64, vp, i64, i32, archp, i32, vp, vp, i64, i64, i64, vp]
     lib.nngp_kernel_diag.argtypes = [vp, i64, i32, archp, vp, vp, vp]
     lib.nngp_model_create.argtypes = [ctypes.POINTER(vp), i64, i64, i32, i32, archp, i32, dbl, i32]
@@ -102,16 +111,22 @@ def load():
     lib.nngp_gemm_nt_h3.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, i32, vp]
     lib.nngp_trsm_rlt_f32.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp]
+    lib.nngp_comm_unique_id.argtypes = [vp]
+    lib.nngp_comm_create.argtypes = [ctypes.POINTER(vp), vp, i32, i32]
+    lib.nngp_comm_destroy.argtypes = [vp]
+    lib.nngp_comm_library.restype = ctypes.c_char_p
+    lib.nngp_allgather_rows.argtypes = [vp, i64, i64, i32, vp, vp]
+    lib.nngp_bcast.argtypes = [vp, i64, i32, i32, vp, vp]
     for name in ABI_SYMBOLS:
-        if name not in ("nngp_last_error", "nngp_model_factor_shift"):
+        if name not in ("nngp_last_error", "nngp_model_factor_shift", "nngp_comm_library"):
             getattr(lib, name).restype = ctypes.c_int
-    _lib = lib
+    _libs[knobs] = lib
     return lib
 
 
-def check(rc: int):
+def check(rc: int, lib=None):
     if rc != 0:
-        msg = load().nngp_last_error()
+        msg = (lib or load()).nngp_last_error()
         raise NngpError("libnngp_hip: rc=%d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))
 
 

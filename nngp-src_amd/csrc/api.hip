@@ -304,12 +304,12 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
 // N = 32768: M = 128: 21.8 / 20.1, 256: 29.3 / 30.6, 512: 40.6 / 51.5)
 bool use_split_solves(const nngp_model* m, int64_t mp) {
     return m->split.l_ready && m->split.planes_b != nullptr && mp <= m->split.mb_cap && m->tri.bs == m->split.k_cap &&
-           g_debug[7] == 0 && mp >= 256 && mp * m->np >= 7000000;
+           NNGP_KNOB(7) == 0 && mp >= 256 && mp * m->np >= 7000000;
 }
 
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
 int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
-    if (g_debug[7] == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
+    if (NNGP_KNOB(7) == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
         return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->ld, m->dinv, m->np, s);
     if (use_split_solves(m, mp))
         return trsm_rlt_blocks_h3(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, m->split, s);
@@ -319,7 +319,7 @@ int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
 // b32 [mp, np] <- b32 (L L^T)^-1
 int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     NNGP_TRY(apply_forward_f32(m, mp, s));
-    if (g_debug[7] == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+    if (NNGP_KNOB(7) == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
     if (use_split_solves(m, mp)) {
         NNGP_TRY(ensure_lt_split(m, s));
         return trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt_ready ? m->lt32 : nullptr, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
@@ -397,11 +397,13 @@ extern "C" {
 
 int nngp_version(void) { return NNGP_ABI_VERSION; }
 
+#ifdef NNGP_TIMING_KNOBS
 int nngp_debug_set(int32_t key, int32_t value) {
     NNGP_REQUIRE(key >= 0 && key < 8, "debug_set: key out of range");
-    g_debug[key] = value;
+    g_knobs[key].store(value, std::memory_order_relaxed);
     return 0;
 }
+#endif
 
 const char* nngp_last_error(void) { return g_err; }
 
@@ -672,7 +674,7 @@ int nngp_model_factor(nngp_model* m, void* stream) {
         int32_t cl = 0;
         NNGP_HIP_CHECK(hipMemcpyAsync(&cl, m->clamped, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         NNGP_HIP_CHECK(hipStreamSynchronize(s));
-        if (cl == 0 || attempt == 4 || g_debug[6] == 1) break;
+        if (cl == 0 || attempt == 4 || NNGP_KNOB(6) == 1) break;
         m->reg_fac *= 16.0;
         set_split_scale(m);
     }
@@ -804,8 +806,8 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
     m->iters = 0;
     m->relres = 0.0;
     m->cg_partial = false;
-    const bool partial = allow_partial && m->ny == 1 && m->pend_tol < 1e-3 && g_debug[0] != 128;
-    const double tol = partial ? ((g_debug[3] >= 41 && g_debug[3] <= 52) ? pow(10.0, -(double)(g_debug[3] - 40)) : kPartialTol) : m->pend_tol;
+    const bool partial = allow_partial && m->ny == 1 && m->pend_tol < 1e-3 && NNGP_KNOB(0) != 128;
+    const double tol = partial ? ((NNGP_KNOB(3) >= 41 && NNGP_KNOB(3) <= 52) ? pow(10.0, -(double)(NNGP_KNOB(3) - 40)) : kPartialTol) : m->pend_tol;
     if (m->solve_ahead > 0) {
         const int ahead = m->solve_ahead;
         m->solve_ahead = 0;
@@ -849,13 +851,14 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
     NNGP_HIP_CHECK(hipEventRecord(m->ev_ready, s));  // everything the solve reads has been enqueued on `s`
     m->solve_pending = true;
     m->solved = true;
-    if (g_debug[7] == 3) return run_pending_solve(m, s, true);  // timing experiment: solve now, in stream order
+    if (NNGP_KNOB(7) == 3) return run_pending_solve(m, s, true);  // timing experiment: solve now, in stream order
+    if (NNGP_KNOB(0) & 32) return run_pending_solve(m, s, true, true);  // ... early-stopped (a later mean-only predict resumes it)
     // (measured and dropped: starting the first six CG iterations here, on the solve stream, without waiting on the host
     // (pcg_begin / pcg_finish) -- the CG then runs beside the posterior's float32 solves instead of under its float64
     // GEMMs, and the two latency-bound kernel chains slow each other down by what the overlap gains: N = 32768: 155.8 vs
     // 152.5 ms per step, N = 8192: 16.0 vs 15.3, N = 65536: 716 vs 706; the same with the solve stream at normal priority.
     // Debug key 0 = 64 enables it for timing.)
-    if (m->ny == 1 && g_debug[0] == 64) {
+    if (m->ny == 1 && NNGP_KNOB(0) == 64) {
         const int ahead = m->pend_max_iters < kSolveAhead ? m->pend_max_iters : kSolveAhead;
         NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_ready, 0));
         NNGP_TRY(launch_strided_copy_f64(m->y, 1, m->pcg.bcol, 1, m->n, m->solve_stream));
@@ -1005,7 +1008,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // Row flag: a LOWER bound of the remaining relative variance error above this value (debug key 6 = e >= 2: 10^-e).
     // The bound is loose -- measured 1e-10 where the error is 4e-7 (N = 32768, scripts/flag_study.py) -- so it is only the
     // backstop for fits whose alpha solve says nothing about the conditioning (e.g. y = 0 converges at once).
-    const double kFlagThr = (g_debug[6] >= 2 && g_debug[6] <= 30) ? pow(10.0, -(double)g_debug[6]) : 1e-8;
+    const double kFlagThr = (NNGP_KNOB(6) >= 2 && NNGP_KNOB(6) <= 30) ? pow(10.0, -(double)NNGP_KNOB(6)) : 1e-8;
     auto cov_part = [&]() -> int {
     if (full) NNGP_TRY(ensure_full_cov_capacity(m, mt));
     NNGP_TRY(launch_diag_from_q(qt, mt, m->arch, m->tt_diag, nullptr, s));  // NNGP K(x_t, x_t)
@@ -1055,8 +1058,8 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         //   level 1: one sweep, cov = K_tt - sym(Z K_dt)  (error ~ rho * float32 error); diag only: see below
         //   level L >= 2: L-1 sweeps, then with R = K_td - Z A:  k_i^T A^-1 k_j = sym(z_i . (k_j + r_j)) + O(err^2)
         const int level = (serving && m->var_refine < 2) ? 2 : m->var_refine;  // the inverse needs the second-order formula
-        const bool second_order = level >= 2;
-        if (!full && level == 1) {
+        const bool second_order = level >= 2 || (!full && level == 1);
+        if (!full && level == 1 && NNGP_KNOB(5) == 1) {
             // diag, one float64 product: with z0 from the float32 factor, r0 = k - A z0 and d = M^-1 r0,
             //   k^T A^-1 k = z0.(k + r0) + e0^T A e0  and  e0^T A e0 = r0^T A^-1 r0 ~ r0.d   (error: rho e0^T A e0;
             // 70x better than the first-order formula at z0 + d for the same work: 2e-5 instead of 1.4e-3 at N = 32768)
@@ -1163,7 +1166,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // Then the rows go on by preconditioned CG until each has converged, and the covariance is formed again.
     // (debug key 6 = 1: fixed sweeps only.)
     m->cov_iters = 0;
-    if (check_kind != 0 && g_debug[6] != 1) {
+    if (check_kind != 0 && NNGP_KNOB(6) != 1) {
         // Iterations of the alpha solve against the variance error of the fixed sweeps, 72 random fits of
         // tests/test_gpu_parity.py (N <= 5200): <= 5: <= 1e-7, 6: <= 1e-5, 7: <= 5e-5, >= 9: up to 8e-2; the bench sizes
         // need 5 (N = 32768) and 6 (N = 65536).  NTK covariance has no second-order formula: stricter.
@@ -1241,7 +1244,7 @@ int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const fl
     if (rc == 0) rc = launch_split_rows(b, ldb, n, k, scale, pb, ldp, s);
     if (rc == 0)
         rc = launch_gemm_nt_h3(c, ldc, pa, pb, ldp, m, n, k, alpha / (scale * scale), beta, lower_only != 0, 0, counters,
-                               g_debug[4] > 0 ? g_debug[4] : 0, s);
+                               NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 0, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(pa);
     return rc;

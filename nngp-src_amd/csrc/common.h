@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 
@@ -12,7 +13,9 @@ namespace nngp {
 constexpr int TB = 128;  // Cholesky / GEMM tile edge; all float32 device matrices are padded to it
 
 void set_error(const char* fmt, ...);
-// Timing-experiment switches (nngp_debug_set / NNGP_DEBUG="key=value,..." in bench.py); all zero in normal operation:
+// Timing-experiment switches.  They exist ONLY in libnngp_hip_knobs.so (built with -DNNGP_TIMING_KNOBS for scripts/ and the
+// A/B tests, entry point nngp_debug_set); in the product library NNGP_KNOB(i) is the constant 0 and every branch on it is
+// compiled out.  Keys:
 //   0  bit mask: 1, 2, 4 leaf-kernel ablations (wrong results); 1, 2, 8 split-float16 GEMM ablations (no loads / no MFMA /
 //      no C traffic; wrong results); 64 = start the alpha CG ahead, without waiting on the host (nngp_model_solve);
 //      128 = never stop the alpha CG early (no mean correction through the covariance rows)
@@ -29,7 +32,14 @@ void set_error(const char* fmt, ...);
 //      of a broken-down factorisation; 2..30 = e: row-flag threshold 10^-e of the adaptive covariance
 //   7  1 = 128-wide recursion in the posterior solves; any non-zero value = float32 solve path; 3 = CG solve in stream
 //      order instead of deferred
-extern int g_debug[8];
+//   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
+//   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
+#ifdef NNGP_TIMING_KNOBS
+extern std::atomic<int> g_knobs[8];
+#define NNGP_KNOB(i) (nngp::g_knobs[i].load(std::memory_order_relaxed))
+#else
+#define NNGP_KNOB(i) 0
+#endif
 
 #define NNGP_HIP_CHECK(expr)                                                              \
     do {                                                                                  \

@@ -180,7 +180,7 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
     // 256 compute units (two workgroups each) have work; partial tiles go to a stream-ordered scratch buffer and are
     // summed in a fixed order.  Measured (serving mode, 128 queries, N = 10800): see DESIGN.md section 7.
     int ksplit = 1;
-    if (kmode != 2 && tm * tn <= 256 && k / DBK >= 128 && g_debug[5] != 9) {
+    if (kmode != 2 && tm * tn <= 256 && k / DBK >= 128 && NNGP_KNOB(5) != 9) {
         ksplit = (int)(512 / (tm * tn));
         if (ksplit > 8) ksplit = 8;
         while (ksplit > 1 && (k / DBK) / ksplit < 32) --ksplit;

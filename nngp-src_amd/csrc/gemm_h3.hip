@@ -21,6 +21,8 @@
 // groups of gfx950).  K blocks are consumed from the high end down (accumulation order of the Cholesky updates, see
 // gemm_f32.hip).  The grid is persistent: one workgroup per compute unit (128 KB of LDS each) pulls tiles from per-XCD
 // work counters, which lets the caller keep a few compute units free for a concurrent latency-critical stream.
+#include <atomic>
+
 #include "common.h"
 
 namespace nngp {
@@ -407,18 +409,20 @@ int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64
     NNGP_REQUIRE(m < 2147483647LL && n < 2147483647LL, "gemm_nt_h3: matrix too large");
     // tile-block shape (debug key 5 = 10 + variant for A/B timing); 4 x 4 measured best at N = 8k .. 32k
     static const int kOrders[][2] = {{4, 4}, {8, 4}, {4, 8}, {2, 8}, {8, 2}, {8, 8}, {2, 16}, {2, 4}};
-    const int variant = (g_debug[5] >= 10 && g_debug[5] < 18) ? g_debug[5] - 10 : 0;
+    const int variant = (NNGP_KNOB(5) >= 10 && NNGP_KNOB(5) < 18) ? NNGP_KNOB(5) - 10 : 0;
     const int br = kOrders[variant][0], bc = kOrders[variant][1];
     int64_t nblk = 0;
     for (int64_t gr = 0; gr < (tm + br - 1) / br; ++gr)
         nblk += h3_block_cols((int)gr, br, bc, (int)tm, (int)tn, lower_only, (int)((diag_shift + HT - 1) / HT));
     const int64_t slots_per_xcd = ((nblk + 7) / 8) * br * bc;
     NNGP_REQUIRE(slots_per_xcd < 2147483647LL / 8, "gemm_nt_h3: too many tiles");
-    static int ncu = 0;
+    static std::atomic<int> ncu_cached{0};  // compute units of the device (every MI355X of a node has the same count)
+    int ncu = ncu_cached.load(std::memory_order_relaxed);
     if (ncu == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        int dev = 0, count = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess &&
+               hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && count > 0) ? count : 256;
+        ncu_cached.store(ncu, std::memory_order_relaxed);
     }
     int64_t grid = ncu - reserve_cus;
     if (grid > slots_per_xcd * 8) grid = slots_per_xcd * 8;
@@ -428,10 +432,10 @@ int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64
     if (lower_only)
         hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
                            (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters, (int)slots_per_xcd,
-                           g_debug[0] & 11, row_alpha);
+                           NNGP_KNOB(0) & 11, row_alpha);
     else
         hipLaunchKernelGGL((k_gemm_nt_h3<false>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
-                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, g_debug[0] & 11, row_alpha);
+                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, NNGP_KNOB(0) & 11, row_alpha);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -338,7 +338,7 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
     // Gram 0.038 ms -- on gfx950 the float64 MFMA rate EQUALS the float64 VALU rate (78.6 TF), so the matrix cores buy
     // nothing here and add an LDS re-tiling pass; the VALU form is the default.  Where the 11 ms go at d=128, n_relu=3:
     // 3.0 ms stores + tile overhead, 3.3 ms Gram, 1.7 ms per ReLU layer (sqrt + atan2 in float64).
-    if (g_debug[3] == 3)
+    if (NNGP_KNOB(3) == 3)
         hipLaunchKernelGGL(k_build<true>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
     else
         hipLaunchKernelGGL(k_build<false>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);

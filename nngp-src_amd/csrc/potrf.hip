@@ -13,13 +13,16 @@
 // trailing sub-blocks updated with v_mfma_f32_32x32x2_f32.  The 128x128 inverse is assembled from the
 // 32x32 inverses by block forward substitution on the matrix cores.  LDS row stride is 129 floats, which
 // makes row-wise and column-wise 4-byte fragment reads conflict free.
+#include <atomic>
 #include <new>
 
 #include "common.h"
 
 namespace nngp {
 
-int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // timing experiments only (nngp_debug_set); 0 = product behaviour
+#ifdef NNGP_TIMING_KNOBS
+std::atomic<int> g_knobs[8];  // timing experiments only (libnngp_hip_knobs.so: nngp_debug_set); zero-initialised
+#endif
 
 namespace {
 
@@ -230,10 +233,10 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
 }  // namespace
 
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s) {
-    if (g_debug[3] != 1)  // variant 1 (scalarised broadcasts) measured 57 us vs 84 us for variant 0
-        hipLaunchKernelGGL(k_potrf_leaf<1>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, g_debug[0]);
+    if (NNGP_KNOB(3) != 1)  // variant 1 (scalarised broadcasts) measured 57 us vs 84 us for variant 0
+        hipLaunchKernelGGL(k_potrf_leaf<1>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, NNGP_KNOB(0));
     else
-        hipLaunchKernelGGL(k_potrf_leaf<0>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, g_debug[0]);
+        hipLaunchKernelGGL(k_potrf_leaf<0>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, NNGP_KNOB(0));
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -297,9 +300,9 @@ int lookahead_create(LookAhead** out) {
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    const int panel_cus = g_debug[4] > 0 ? g_debug[4] : 32;
+    const int panel_cus = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
     bool masked = false;
-    if (g_debug[5] == 2 && ncu >= 64 && panel_cus < ncu) {
+    if (NNGP_KNOB(5) == 2 && ncu >= 64 && panel_cus < ncu) {
         const int words = (ncu + 31) / 32;
         uint32_t mp[16] = {0}, mu[16] = {0};
         // mask bit i addresses CU (i / 8) of XCD (i % 8) (measured: masks that thin out one XCD make it the straggler of
@@ -353,19 +356,19 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                         LookAhead* la, SplitWork* sw, hipStream_t user) {
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
     // block-column width: 1024 measured best at N = 32768 (119.4 ms; 2048: 121.3, 4096: 123.2, recursion only: 125)
-    int64_t nb = g_debug[1] > 0 ? (int64_t)g_debug[1] : kLookAheadNb;
+    int64_t nb = NNGP_KNOB(1) > 0 ? (int64_t)NNGP_KNOB(1) : kLookAheadNb;
     nb = (nb / TB) * TB;
     // large trailing updates on the float16 matrix pipe (gemm_h3.hip) unless the workspace is missing / too small or
     // debug key 2 == 2 asks for the float32-MFMA updates (A/B timing)
     const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && sw->k_cap == nb && sw->rows_cap >= n + 256 &&
-                    sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && g_debug[2] != 2;
+                    sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && NNGP_KNOB(2) != 2;
     if (sw != nullptr) sw->l_ready = sw->lt_ready = false;
     // (measured and dropped: solving the panel rows in four row chunks on a third stream, each chunk's trailing update
     // starting as soon as it is solved -- 64.8 vs 59.2 ms: four smaller split-float16 launches lose more in their tails
     // than the overlap gains)
     // (measured twice and dropped: inverting each diagonal block on the panel stream as it is factored -- neutral, 59.1 vs
     // 58.9 ms, and 58.1 vs 57.9 ms with CUs reserved for the panel stream -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
-    if (la == nullptr || g_debug[2] == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
+    if (la == nullptr || NNGP_KNOB(2) == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
@@ -400,8 +403,8 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
             // on it runs on the float16 pipe too: X1 is split straight into its place in this block column's planes (the
             // trailing update needs it there anyway), L21 into the planes' unused rows of the diagonal block.  (Block
             // column 0 stays on the float32 MFMA: same-sign data, see below.  Debug key 2 = 3: float32 product.)
-            const bool h3_panel = h3 && k > 0 && nbk == nb && nb == 1024 && m - nb2 >= 2048 && g_debug[2] != 3 &&
-                                  !(g_debug[3] >= 10 && g_debug[3] < 20 && k < g_debug[3] - 10);
+            const bool h3_panel = h3 && k > 0 && nbk == nb && nb == 1024 && m - nb2 >= 2048 && NNGP_KNOB(2) != 3 &&
+                                  !(NNGP_KNOB(3) >= 10 && NNGP_KNOB(3) < 20 && k < NNGP_KNOB(3) - 10);
             panel_split_done = false;
             if (h3_panel) {
                 const int64_t ldp = 4 * sw->k_cap, h = nbk / 2, mr = m - nb2;
@@ -413,7 +416,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 if (rc == 0) rc = launch_split_rows(akk + h * ld, ld, h, h, sw->scale, pk + (o + h) * ldp, ldp, la->update);  // L21
                 if (rc == 0)
                     rc = launch_gemm_nt_h3(b + h, ld, xrows, pk + (o + h) * ldp, ldp, mr, h, h, -1.0f / (sw->scale * sw->scale), 1.0f,
-                                           false, 0, sw->counters, g_debug[4] > 0 ? g_debug[4] : 32, la->update);
+                                           false, 0, sw->counters, NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32, la->update);
                 if (rc == 0) rc = trsm_rlt_f32(b + h, ld, mr, akk + h * ld + h, ld, dk + (h / TB) * TB * TB, h, la->update);  // X2
                 if (rc == 0) rc = launch_split_rows(b + h, ld, mr, h, sw->scale, xrows + h * 4, ldp, la->update);
                 if (rc == 0)  // the rows solved first (critical path) go into the planes as well
@@ -430,15 +433,15 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
             // N = 32768 (Cholesky ms / CG iterations / level-2 variance error): lead 0: 59.8 / 7 / 1.6e-5, 128: 61.0 / 6 /
             // 4.1e-7, 256: 61.9 / 5 / 4.0e-7, 512: 63.6 / 6, whole column: 63.6 / 5 / 4.0e-7.
             // (debug key 3 = 10 + n: n whole block columns on float32; 20 + c: lead = 128 c)
-            const bool f32_first = !h3 || (g_debug[3] >= 10 && g_debug[3] < 20 && k < g_debug[3] - 10);
+            const bool f32_first = !h3 || (NNGP_KNOB(3) >= 10 && NNGP_KNOB(3) < 20 && k < NNGP_KNOB(3) - 10);
             int64_t lead = 0;
-            if (h3 && !f32_first && k == 0) lead = (g_debug[3] >= 20 && g_debug[3] < 28) ? 128 * (int64_t)(g_debug[3] - 20) : 256;
+            if (h3 && !f32_first && k == 0) lead = (NNGP_KNOB(3) >= 20 && NNGP_KNOB(3) < 28) ? 128 * (int64_t)(NNGP_KNOB(3) - 20) : 256;
             if (lead > nbk - 128) lead = 0;
             if (!f32_first) {
                 // the persistent GEMM grid leaves `reserve` compute units to the panel stream, whose small kernels
                 // otherwise queue behind 128-KB-LDS workgroups (measured at N = 32768: 0/8/16 -> 62.7 ms, 32 -> 58.7,
                 // 24 -> 65.0, 48 -> 58.8, 64 -> 60.4; debug key 4 overrides)
-                const int reserve = g_debug[4] > 0 ? g_debug[4] : 32;
+                const int reserve = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
                 // one launch: rows [nb2, m) x columns [0, m) of the trailing matrix, on or below its diagonal
                 // (the split copy of block column k stays in place, rows at their global index: the blocked triangular
                 // solves of the posterior read it again)
@@ -505,7 +508,7 @@ int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, in
     // panel is split once, when its first update arrives; the leading columns of the first panel stay on the float32
     // MFMA (accumulator truncation on same-sign sums, see potrf_lookahead_f32)
     if (sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && pw == sw->k_cap && po % pw == 0 &&
-        sw->rows_cap >= n + 256 && g_debug[2] != 2 && (n - o) * w >= 96 * 256 * 256) {
+        sw->rows_cap >= n + 256 && NNGP_KNOB(2) != 2 && (n - o) * w >= 96 * 256 * 256) {
         const int64_t ldp = 4 * sw->k_cap;
         char* col = sw->planes + (po / pw) * sw->col_stride;  // rows at their global index
         if (sw->split_panel != po) {

@@ -187,7 +187,7 @@ int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_
 }
 
 int64_t triinv_block(int64_t np) {
-    const int64_t bs = g_debug[6] >= 128 ? (int64_t)g_debug[6] : 1024;  // debug key 6: block size experiment
+    const int64_t bs = NNGP_KNOB(6) >= 128 ? (int64_t)NNGP_KNOB(6) : 1024;  // debug key 6: block size experiment
     return np < bs ? np : bs;
 }
 

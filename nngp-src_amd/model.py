@@ -20,19 +20,28 @@ _COV = {False: _lib.COV_NONE, None: _lib.COV_NONE, "none": _lib.COV_NONE, "diag"
 
 class GPModel:
     def __init__(self, n_cap: int, d: int, w_std, b_std, get: str = "nngp", diag_reg: float = 1e-3,
-                 diag_reg_absolute_scale: bool = False, ny: int = 1, m_cap: int = 0):
+                 diag_reg_absolute_scale: bool = False, ny: int = 1, m_cap: int = 0, knobs: bool = False):
         if get not in _GET:
             raise ValueError("get must be 'nngp' or 'ntk', got %r" % (get,))
-        self.lib = _lib.load()
+        self.lib = _lib.load(knobs)  # knobs=True: the timing-knob build (A/B tests and scripts/ only)
         self.device = _lib.require_gpu()
         self.get, self.d, self.ny, self.n_cap = get, int(d), int(ny), int(n_cap)
         self.arch = _lib.make_arch(w_std, b_std)
         self.handle = ctypes.c_void_p()
-        _lib.check(self.lib.nngp_model_create(ctypes.byref(self.handle), int(n_cap), int(m_cap), int(d), int(ny),
+        self._check(self.lib.nngp_model_create(ctypes.byref(self.handle), int(n_cap), int(m_cap), int(d), int(ny),
                                               ctypes.byref(self.arch), _GET[get], float(diag_reg),
                                               int(bool(diag_reg_absolute_scale))))
         self.n = 0
         self._keep = []  # device tensors that must outlive asynchronous work
+
+    def _check(self, rc: int):
+        _lib.check(rc, self.lib)
+
+    def debug_set(self, key: int, value: int):
+        """Timing-experiment switch; only a model created with ``knobs=True`` has it (libnngp_hip_knobs.so)."""
+        if not hasattr(self.lib, "nngp_debug_set"):
+            raise _lib.NngpError("the product library has no nngp_debug_set: create the model with knobs=True")
+        self._check(self.lib.nngp_debug_set(int(key), int(value)))
 
     # ---- lifetime ----
     def close(self):
@@ -58,7 +67,7 @@ class GPModel:
             raise ValueError("x_train has %d rows; the model was created for 1..%d" % (xd.shape[0], self.n_cap))
         self.n = int(xd.shape[0])
         self._keep = [xd, yd]
-        _lib.check(self.lib.nngp_model_set_train(self.handle, _lib.ptr(xd), _lib.ptr(yd), self.n, _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_set_train(self.handle, _lib.ptr(xd), _lib.ptr(yd), self.n, _lib.stream_ptr()))
 
     def append(self, x_new, y_new, solve: bool = True):
         """Add training rows to a fitted model: their kernel rows are built and the factor is extended in place
@@ -72,7 +81,7 @@ class GPModel:
             return self
         if self.n + b > self.n_cap:
             raise ValueError("append: %d + %d rows exceed the capacity %d" % (self.n, b, self.n_cap))
-        _lib.check(self.lib.nngp_model_append(self.handle, _lib.ptr(xd), _lib.ptr(yd), b, _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_append(self.handle, _lib.ptr(xd), _lib.ptr(yd), b, _lib.stream_ptr()))
         self.n += b
         if solve:
             self.solve()
@@ -80,48 +89,48 @@ class GPModel:
 
     def build_rows(self, row_begin: int = 0, row_end: int = None):
         row_end = self.n if row_end is None else row_end
-        _lib.check(self.lib.nngp_model_build_rows(self.handle, int(row_begin), int(row_end), _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_build_rows(self.handle, int(row_begin), int(row_end), _lib.stream_ptr()))
 
     def factor(self):
-        _lib.check(self.lib.nngp_model_factor(self.handle, _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_factor(self.handle, _lib.stream_ptr()))
 
     # block-column pieces of factor() for the multi-GPU Cholesky (distributed.distributed_factor)
     def factor_begin(self):
-        _lib.check(self.lib.nngp_model_factor_begin(self.handle, _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_factor_begin(self.handle, _lib.stream_ptr()))
 
     def factor_panel(self, col0: int, width: int):
-        _lib.check(self.lib.nngp_model_factor_panel(self.handle, int(col0), int(width), _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_factor_panel(self.handle, int(col0), int(width), _lib.stream_ptr()))
 
     def factor_update(self, panel_col0: int, panel_width: int, col0: int, width: int):
-        _lib.check(self.lib.nngp_model_factor_update(self.handle, int(panel_col0), int(panel_width), int(col0), int(width),
+        self._check(self.lib.nngp_model_factor_update(self.handle, int(panel_col0), int(panel_width), int(col0), int(width),
                                                      _lib.stream_ptr()))
 
     def factor_end(self):
-        _lib.check(self.lib.nngp_model_factor_end(self.handle, _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_factor_end(self.handle, _lib.stream_ptr()))
 
     def factor_buffers(self):
         """(a32 [np, np] float32 view, dinv [np/128, 128, 128] float32 view) of the library-owned factor buffers."""
         a, ld, d = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p()
-        _lib.check(self.lib.nngp_model_factor_buffers(self.handle, ctypes.byref(a), ctypes.byref(ld), ctypes.byref(d)))
+        self._check(self.lib.nngp_model_factor_buffers(self.handle, ctypes.byref(a), ctypes.byref(ld), ctypes.byref(d)))
         np_ = self.info()["n_padded"]  # rows/columns in use; the row stride ld is the padded capacity
         a32 = _wrap_device(a.value, np_ * ld.value, self.device, "<f4").view(np_, ld.value)[:, :np_]
         dinv = _wrap_device(d.value, (np_ // 128) * 128 * 128, self.device, "<f4").view(np_ // 128, 128, 128)
         return a32, dinv
 
     def solve(self, max_iters: int = 0, tol: float = 0.0):
-        _lib.check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 
     def set_refine(self, sweeps: int):
         """Precision level of the posterior covariance: 0 = float32 solve only; 1 = one float64 residual, second-order
         formula at the float32 solution plus its preconditioned remainder (diag; full covariance: one sweep);
         L >= 2 = L-1 correction sweeps plus the second-order formula (default 2)."""
-        _lib.check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
+        self._check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 
     def prepare_serving(self):
         """Build the explicit float64 inverse of K + reg I once (``nngp_model_prepare_serving``): later ``predict`` calls
         cost one float64 product instead of blocked solves and correction sweeps.  Dropped by fit / append."""
-        _lib.check(self.lib.nngp_model_prepare_serving(self.handle, _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_prepare_serving(self.handle, _lib.stream_ptr()))
         return self
 
     def factor_shift(self) -> float:
@@ -145,20 +154,20 @@ class GPModel:
         """(torch view of the float64 train-train kernel in HBM, ld).  The view is [n, ld], or every row the
         allocation can hold at this ld when ``all_rows`` (the RCCL all-gather writes whole chunks)."""
         p, ld = ctypes.c_void_p(), ctypes.c_int64()
-        _lib.check(self.lib.nngp_model_kernel_buffer(self.handle, ctypes.byref(p), ctypes.byref(ld)))
+        self._check(self.lib.nngp_model_kernel_buffer(self.handle, ctypes.byref(p), ctypes.byref(ld)))
         np_cap = (self.n_cap + 127) // 128 * 128
         rows = (np_cap * np_cap) // ld.value if all_rows else self.n
         return _wrap_device(p.value, rows * ld.value, self.device, "<f8").view(rows, ld.value), ld.value
 
     def info(self) -> dict:
         fi = _lib.NngpFitInfo()
-        _lib.check(self.lib.nngp_model_info(self.handle, ctypes.byref(fi)))
+        self._check(self.lib.nngp_model_info(self.handle, ctypes.byref(fi)))
         return {k: getattr(fi, k) for k, _ in fi._fields_}
 
     def alpha(self):
         import torch
         out = torch.empty((self.n, self.ny), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.nngp_model_alpha(self.handle, _lib.ptr(out), _lib.stream_ptr()))
+        self._check(self.lib.nngp_model_alpha(self.handle, _lib.ptr(out), _lib.stream_ptr()))
         return out
 
     # ---- predict_fn(x_test, get, compute_cov) ----
@@ -180,7 +189,7 @@ class GPModel:
         elif mode == _lib.COV_FULL:
             out = torch.empty((m, m), dtype=torch.float64, device=self.device)
         if m > 0:
-            _lib.check(self.lib.nngp_model_predict(self.handle, _lib.ptr(xt), m, mode, _lib.ptr(mean), _lib.ptr(out),
+            self._check(self.lib.nngp_model_predict(self.handle, _lib.ptr(xt), m, mode, _lib.ptr(mean), _lib.ptr(out),
                                                    _lib.stream_ptr()))
         if as_numpy:
             mean = mean.cpu().numpy()

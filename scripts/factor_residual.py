@@ -1,5 +1,6 @@
 """Backward error of the float32 Cholesky factor, || L L^T - (K + reg I) ||_F / || K + reg I ||_F, for the split-float16
 trailing updates (default) and the float32-MFMA ones (debug key 2 = 2).  Float64 reference product on the GPU."""
+import os; os.environ.setdefault("NNGP_KNOBS", "1")  # timing-knob build of the library
 import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

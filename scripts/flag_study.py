@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where does the row flag of the adaptive covariance (k_rows_prepare) fire?  Sweeps its threshold (debug key 6) at a
 bench-sized problem and reports whether predict went on by CG (cov_iters) and what that changed."""
+import os; os.environ.setdefault("NNGP_KNOBS", "1")  # timing-knob build of the library
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Where the kernel-build time goes: symmetric N x N build timed for several (d, n_relu) on the GPU box."""
+import os; os.environ.setdefault("NNGP_KNOBS", "1")  # timing-knob build of the library
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """GPU micro-benchmarks of the building blocks (run on the GPU box): GEMM shapes, Cholesky leaf, potrf sizes."""
+import os; os.environ.setdefault("NNGP_KNOBS", "1")  # timing-knob build of the library
 import json
 import os
 import sys

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("NNGP_KNOBS", "1")  # timing-knob build of the library
 #!/usr/bin/env python3
 """Early-stopped alpha CG: stopping tolerance (debug key 3 = 40 + e -> 10^-e) against step time and the error of the corrected
 mean mu = K_td a_k + Z r_k relative to the fully converged solve."""

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("NNGP_KNOBS", "1")  # timing-knob build of the library
 #!/usr/bin/env python3
 """A/B of one predict configuration under a debug key (NNGP_AB="key=value"): time per call, back to back."""
 import os, sys, time

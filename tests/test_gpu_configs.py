@@ -1,0 +1,152 @@
+"""-m gpu: every BASELINE.json config at ITS OWN size, through the C ABI, against the float64 C oracle.
+
+An O(N^3) CPU factorisation does not finish in test time at N = 32768 / 65536, so the checks below use what the
+oracle CAN do at full size (the C restatement builds kernel rows at ~17 M entries/s per core) and are each
+independent of the GPU's own kernel matrix and factor:
+
+* ``info``: no clamped pivot, float64 residual of the alpha solve < 1e-10 (the GPU's own claim -- checked below);
+* the kernel buffer in HBM: 8 rows against oracle rows at 1e-11, bitwise symmetry of corner blocks;
+* alpha: ``K_oracle[rows] alpha + reg alpha[rows] = y[rows]`` on a sample of rows, with ``reg`` recomputed from the
+  oracle's diagonal;
+* posterior mean of ALL M test queries against ``K_oracle(x_test, X) alpha``;
+* posterior variance, level 2 (default) against level 3 on a 64-query subset, and INDEPENDENTLY for a few queries c:
+  a second fit with y := k_c (ny = 4 columns) gives candidate solutions z_c = A^-1 k_c; the oracle streams the
+  whole N x N kernel once (rows in blocks, never stored), forms A z_c in float64, and then
+  ``k^T A^-1 k = 2 z.k - z^T A z`` up to ``r^T A^-1 r <= |r|^2 / reg`` with r = k - A z -- a bound the CPU evaluates
+  itself.  NTK: the same with Theta for the residual and the NNGP kernel for ``z^T K z - 2 k.z``.
+
+Sizes: SURVEY.md 8d (cfg2 N=8192 d=64; cfg3 N=32768 d=128 n_relu=3; cfg4 N=65536 d=128 n_relu=3, the one-GPU leg
+of the 8-GPU config; cfg5 N=16384 d=256 NTK with the join block).  Reference call sites: train.py:153-203.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import c_oracle  # noqa: E402
+import nngp_oracle as o  # noqa: E402
+from nngp_src_amd import synth  # noqa: E402
+from nngp_src_amd.model import GPModel  # noqa: E402
+
+# name: (N, d, n_relu, get, M, join_block, stream the whole oracle kernel for the variance check)
+CONFIGS = {
+    "cfg2": (8192, 64, 1, "nngp", 1024, False, True),
+    "cfg3": (32768, 128, 3, "nngp", 1024, False, True),
+    "cfg5": (16384, 256, 1, "ntk", 1024, True, True),
+    # 65536^2 oracle entries = ~2 min on the box's 16 cores: on request (NNGP_FULL_ORACLE=1; log kept in profiles/)
+    "cfg4": (65536, 128, 3, "nngp", 1024, False, os.environ.get("NNGP_FULL_ORACLE", "0") == "1"),
+}
+
+
+def _oracle_rows(x_rows, x, get, a):
+    return c_oracle.kernel_build(x_rows, x, get, a.w_std, a.b_std)
+
+
+def _stream_products(x, a, gets, vecs, block=2048):
+    """{get: K_get(X, X) @ vecs} with the oracle kernel built block-row by block-row (never stored)."""
+    n = x.shape[0]
+    out = {g: np.empty((n, vecs.shape[1])) for g in gets}
+    for r0 in range(0, n, block):
+        r1 = min(n, r0 + block)
+        for g in gets:
+            out[g][r0:r1] = _oracle_rows(x[r0:r1], x, g, a) @ vecs
+    return out
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg5", "cfg4"])
+def test_baseline_config_at_full_size(name):
+    n, d, n_relu, get, m, join_block, stream = CONFIGS[name]
+    c_oracle.set_threads(min(16, os.cpu_count() or 1))
+    a = o.make_arch(n_relu)
+    x, y = synth.synthetic_queries(n, d, seed=0, join_block=join_block)
+    xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
+    log = {"config": name, "N": n, "d": d, "n_relu": n_relu, "get": get, "M": m}
+
+    model = GPModel(n, d, a.w_std, a.b_std, get=get, diag_reg=1e-3, m_cap=m)
+    model.fit(x, y)
+    mean, var = model.predict(xt, cov="diag")  # default precision level, the early-stopped CG + mean correction path
+    info = model.info()
+    assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+    log.update(cg_iters=info["refine_iters"], rel_residual=info["rel_residual"], cov_iters=model.cov_iters())
+
+    # regulariser: diag_reg * mean of the oracle's diagonal (relative scale, train.py:171-172 default)
+    q = np.sum(x * x, axis=1) / d
+    kd, td = o.diag_kernel(q, a)
+    reg = 1e-3 * float(np.mean(kd if get == "nngp" else td))
+    assert abs(info["reg"] - reg) <= 1e-12 * reg
+
+    # kernel buffer: rows against the oracle, symmetry of corner blocks
+    kbuf, _ = model.kernel_buffer()
+    rows8 = np.array([0, 1, 127, 128, n // 2 + 3, n - 130, n - 2, n - 1])
+    np.testing.assert_allclose(kbuf[rows8, :n].cpu().numpy(), _oracle_rows(x[rows8], x, get, a), rtol=1e-11, atol=0)
+    for r0, c0 in ((0, 0), (n - 512, 0), (n - 512, n - 512), (n // 2 - 100, n // 3)):
+        blk, blk_t = kbuf[r0:r0 + 512, c0:c0 + 512].cpu().numpy(), kbuf[c0:c0 + 512, r0:r0 + 512].cpu().numpy()
+        assert np.array_equal(blk, blk_t.T)
+
+    # alpha on a sample of rows
+    alpha = model.alpha().cpu().numpy()
+    rng = np.random.default_rng(5)
+    rows = np.sort(rng.choice(n, 128, replace=False))
+    lhs = _oracle_rows(x[rows], x, get, a) @ alpha + reg * alpha[rows]
+    res_rows = float(np.abs(lhs - y[rows]).max() / np.abs(y).max())
+    assert res_rows < 1e-7, res_rows
+    log["alpha_row_residual"] = res_rows
+
+    # posterior mean of every test query against the oracle's cross kernel
+    ktd = _oracle_rows(xt, x, get, a)
+    mean_ref = ktd @ alpha
+    l2 = float(np.linalg.norm(mean - mean_ref) / np.linalg.norm(mean_ref))
+    elem = float(np.max(np.abs(mean - mean_ref) / np.maximum(1.0, np.abs(mean_ref))))
+    assert l2 < 1e-6 and elem < 1e-6, (l2, elem)  # north-star gate: 1e-4
+    log.update(mean_rel_l2=l2, mean_elem=elem)
+
+    # variance: default level against level 3 on a subset
+    sub = np.arange(0, m, m // 64)[:64]
+    model.set_refine(3)
+    _, var3 = model.predict(xt[sub], cov="diag")
+    model.set_refine(2)
+    assert np.all(var3 > 0)
+    lvl = float(np.max(np.abs(var[sub] - var3) / var3))
+    assert lvl < (1e-4 if get == "nngp" else 1e-3), lvl  # SURVEY 8d gate: 1e-3
+    log["var_default_vs_level3"] = lvl
+    model.close()
+    del model, kbuf
+
+    # variance, independent of the GPU's kernel buffer and factor
+    t0 = time.time()
+    chk = sub[:4]
+    kc = np.ascontiguousarray(ktd[chk].T)  # [N, 4] columns k_c of the `get` kernel
+    model4 = GPModel(n, d, a.w_std, a.b_std, get=get, diag_reg=1e-3, ny=4)
+    model4.fit(x, kc)
+    info4 = model4.info()
+    assert info4["clamped_pivots"] == 0 and info4["rel_residual"] < 1e-10, info4
+    z = model4.alpha().cpu().numpy()  # candidates for A^-1 k_c
+    mean4 = model4.predict(xt[chk], cov=False)  # mean of output c at query c = k_c^T A^-1 k_c through the alpha path
+    model4.close()
+    ktt = np.array([_oracle_rows(xt[i:i + 1], xt[i:i + 1], "nngp", a)[0, 0] for i in chk])
+    if get == "nngp":  # the GPU's two routes to the same number: refined covariance rows vs float64 CG solution
+        np.testing.assert_allclose(var[chk], ktt - np.diag(mean4), rtol=2e-4)
+    if stream:
+        gets = ("nngp",) if get == "nngp" else ("ntk", "nngp")
+        prod = _stream_products(x, a, gets, z)
+        az = prod[get] + reg * z
+        r = kc - az
+        relres = np.linalg.norm(r, axis=0) / np.linalg.norm(kc, axis=0)
+        assert relres.max() < 1e-9, relres
+        if get == "nngp":
+            quad = 2.0 * np.sum(z * kc, axis=0) - np.sum(z * az, axis=0)  # k^T A^-1 k - r^T A^-1 r
+            bound = np.sum(r * r, axis=0) / reg
+            var_ref = ktt - quad
+        else:
+            kn = _oracle_rows(xt[chk], x, "nngp", a).T  # NNGP cross kernel columns
+            var_ref = ktt + np.sum(z * prod["nngp"], axis=0) - 2.0 * np.sum(kn * z, axis=0)
+            # first-order sensitivity to the error of z: 2 (K z - k_nngp) . dz,  |dz| <= |r| / reg
+            bound = 2.0 * np.linalg.norm(prod["nngp"] - kn, axis=0) * np.linalg.norm(r, axis=0) / reg
+        assert np.all(bound < 1e-6 * np.abs(var_ref)), (bound, var_ref)
+        err = float(np.max(np.abs(var[chk] - var_ref) / np.abs(var_ref)))
+        assert err < (1e-5 if get == "nngp" else 1e-4), (err, var[chk], var_ref)  # gate: 1e-3
+        log.update(var_vs_streamed_oracle=err, oracle_solution_relres=float(relres.max()), oracle_seconds=round(time.time() - t0, 1))
+    print("CONFIG_CHECK " + repr(log))

@@ -210,12 +210,12 @@ def test_gemm_split_f16_agrees_with_f32_mfma_in_the_cholesky():
     n = 4096
     x, y = synth.synthetic_queries(n, 32, seed=21)
     from nngp_src_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load(knobs=True)  # the A/B switch only exists in libnngp_hip_knobs.so
     res = {}
     for key2 in (0, 2):
         lib.nngp_debug_set(2, key2)
         try:
-            mdl = GPModel(n, 32, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x / 1000.0, y)
+            mdl = GPModel(n, 32, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x / 1000.0, y)
             res[key2] = (mdl.info(), mdl.alpha().cpu().numpy().copy())
             mdl.close()
         finally:
@@ -459,11 +459,11 @@ def test_lookahead_cholesky_matches_recursion():
     n, d = 8192, 32
     x, y = synth.synthetic_queries(n, d, seed=5)
     a = o.make_arch(1)
-    lib = _lib.load()
+    lib = _lib.load(knobs=True)  # the A/B switch only exists in libnngp_hip_knobs.so
     alphas = []
     for disable in (0, 1):
         lib.nngp_debug_set(2, disable)
-        model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
+        model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3, knobs=True).fit(x, y)
         info = model.info()
         assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
         alphas.append(model.alpha().cpu().numpy())
@@ -723,7 +723,7 @@ def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
     ref_model = GPModel(c["n"], c["d"], a.w_std, a.b_std, diag_reg=c["diag_reg"]).fit(x, y)
     _, var_ref = ref_model.predict(xt, cov="diag")
     assert ref_model.info()["refine_iters"] >= 8 and ref_model.cov_iters() > 0
-    model = GPModel(c["n"], c["d"], a.w_std, a.b_std, diag_reg=c["diag_reg"]).fit(x, np.zeros_like(y))
+    model = GPModel(c["n"], c["d"], a.w_std, a.b_std, diag_reg=c["diag_reg"], knobs=True).fit(x, np.zeros_like(y))
     assert model.info()["refine_iters"] <= 1
     mean, var = model.predict(xt, cov="diag")
     assert model.cov_iters() > 0
@@ -733,12 +733,11 @@ def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
     assert model.cov_iters() > 0
     np.testing.assert_allclose(np.diag(cov), var_ref, rtol=1e-6)
     # fixed sweeps only (what levels >= 2 did before): far off
-    from nngp_src_amd import _lib
-    _lib.load().nngp_debug_set(6, 1)
+    model.debug_set(6, 1)  # (the model above runs on libnngp_hip_knobs.so for this switch)
     try:
         _, var_fixed = model.predict(xt, cov="diag")
     finally:
-        _lib.load().nngp_debug_set(6, 0)
+        model.debug_set(6, 0)
     assert model.cov_iters() == 0 and np.max(np.abs(var_fixed - var_ref) / var_ref) > 1e-3
     # x_test=None (estimator.py:37-40): variances at the training rows, against the float64 C oracle
     mean_tr, var_tr = ref_model.predict(None, cov="diag")

@@ -21,10 +21,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.nngp_version() == 1
     header = open(os.path.join(ROOT, "include", "nngp_hip.h")).read()
     declared = set(re.findall(r"\b(nngp_[a-z0-9_]+)\s*\(", header))
-    declared -= {"nngp_model"}
-    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
-    for name in declared:
+    declared -= {"nngp_model", "nngp_comm"}
+    # nngp_debug_set is declared under #ifdef NNGP_TIMING_KNOBS: exported by libnngp_hip_knobs.so only
+    assert declared == set(_lib.ABI_SYMBOLS) | {"nngp_debug_set"}, declared ^ set(_lib.ABI_SYMBOLS)
+    for name in _lib.ABI_SYMBOLS:
         assert hasattr(lib, name), name
+    assert not hasattr(lib, "nngp_debug_set"), "the product library must not export the timing knobs"
+    knobs = _lib.load(knobs=True)
+    for name in _lib.ABI_SYMBOLS + ("nngp_debug_set",):
+        assert hasattr(knobs, name), name
+    assert knobs.nngp_debug_set(99, 1) != 0 and b"key out of range" in knobs.nngp_last_error()
     assert ctypes.sizeof(_lib.NngpArch) == 8 + 2 * 16 * 8
     assert ctypes.sizeof(_lib.NngpFitInfo) == 3 * 8 + 2 * 4 + 2 * 8
 
@@ -42,6 +48,18 @@ def test_argument_validation_without_gpu():
     assert rc != 0 and b"n_dense" in lib.nngp_last_error()
     with pytest.raises(_lib.NngpError):
         _lib.check(rc)
+
+
+def test_comm_entry_points_validate_arguments_without_gpu():
+    """Section-e entry points (RCCL bound lazily by dlopen): argument errors come back as codes, nothing is loaded."""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.nngp_comm_create(ctypes.byref(h), None, 2, 0) != 0 and b"NULL" in lib.nngp_last_error()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.nngp_comm_create(ctypes.byref(h), ident, 2, 5) != 0 and b"world/rank" in lib.nngp_last_error()
+    assert lib.nngp_allgather_rows(None, 8, 8, _lib.DTYPE_F64, None, None) != 0
+    assert lib.nngp_bcast(None, 8, _lib.DTYPE_F32, 0, None, None) != 0
+    assert lib.nngp_comm_destroy(None) == 0
 
 
 def test_product_never_touches_the_oracle():
