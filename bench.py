@@ -5,13 +5,16 @@ One "step" = one pass of the whole hot path over one synthetic batch of encoded 
 resident in HBM: row norms + regulariser, N x N kernel build, float32 MFMA Cholesky, CG solve for alpha
 on the float64 kernel, and the posterior (cross kernel, mean, diag variance) for M test queries.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1] [--mode shard|replicate]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL).  "Strong" scaling: the problem is fixed.
-Default multi-rank mode ("replicate"): every rank runs the fit (build + Cholesky + alpha) on its own GPU and the test
-rows are sharded -- the float64 kernel is built at ~0.9 TB/s on one GPU, faster than xGMI can move it, so no
-data-path collective pays at these sizes.  NNGP_DIST_MODE=shard selects the north-star layout
-instead: row-block kernel shard + one all-gather + block-cyclic Cholesky with one broadcast per block column.
+N = 1: configs[2] (cfg3, N = 32768, the north-star size).  N > 1 (launched by torch.distributed.run, one rank per GPU):
+configs[3] (cfg4, N = 65536) in the layout BASELINE.json's north star names -- rank g builds the row block
+[g N/G, (g+1) N/G) of the float64 kernel, ONE in-place RCCL all-gather over xGMI completes K on every rank
+(nngp_allgather_rows of the C ABI; torch.distributed's nccl all_gather_into_tensor if the library's own communicator
+cannot be created), then the 1-D block-cyclic Cholesky (one broadcast per block column), replicated alpha solve, test
+rows sharded.  "Strong" scaling: the problem is fixed.  The line also carries the three numbers SURVEY.md 8e asks for
+-- sharded build, all-gather, replicated full build -- and, measured after the timed steps in the same invocation,
+the step time of the "replicate" layout (every rank runs the whole fit, no data-path collective) for comparison.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -31,10 +34,11 @@ CONFIGS = {
     "cfg2": (8192, 64, 1, "nngp", 1024, False, "synthetic N=8192, d=64, 3-layer ReLU NNGP (configs[1])"),
     "cfg3": (32768, 128, 3, "nngp", 1024, False, "synthetic N=32768, d=128, 5-layer ReLU NNGP + full Cholesky posterior (configs[2], north-star target)"),
     "cfg4": (65536, 128, 3, "nngp", 1024, False, "synthetic N=65536, d=128, row-block kernel shard + all-gather (configs[3])"),
-    "cfg5": (16384, 256, 1, "ntk", 1024, True, "synthetic join encoding N=16384, d=256, NTK (configs[4]; mean only)"),
+    "cfg5": (16384, 256, 1, "ntk", 1024, True, "synthetic join encoding N=16384, d=256, NTK mean + NTK-ensemble variance (configs[4])"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak (the roofline BASELINE.json's north star names)
 PEAK_F16_MFMA_TFLOPS = 2516.6  # dense f16/bf16 MFMA peak = 16 x the f32 one; the split-float16 GEMM spends 3 products per term
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def flop_model(n, d, m, n_relu):
@@ -47,39 +51,58 @@ def flop_model(n, d, m, n_relu):
             "total": f_k + f_c + f_solve + f_post, "relu_maps": n_relu * n * (n + 1) // 2}
 
 
-def cpu_baseline(n_relu, get):
-    """The C float64/OpenMP oracle ("port") on a bounded sample of the same workload, host cores of this box."""
-    n, d, m = 6144, 128, 256
-    try:  # second opinion on the dominant stage, timed BEFORE the OpenMP oracle spins up its threads:
-        import scipy.linalg  # LAPACK dpotrf through SciPy on an SPD matrix of the same size (BASELINE.md section 2)
-        g = np.random.default_rng(0).standard_normal((n, 256))
-        a = g @ g.T / 256 + np.eye(n)
-        t0 = time.perf_counter()
-        scipy.linalg.cho_factor(a, lower=True, overwrite_a=True, check_finite=False)
-        tl = time.perf_counter() - t0
-        lapack = {"ms": round(tl * 1e3, 1), "gflops": round((n ** 3 / 3) / tl / 1e9, 1),
-                  "note": "scipy.linalg.cho_factor float64 on a random SPD matrix, N=%d" % n}
-        del a, g
-    except Exception as e:  # pragma: no cover
-        lapack = {"error": str(e)}
+def cpu_baseline(n_bench, d, m, n_relu, gpu_ms):
+    """The C float64/OpenMP oracle ("port") on bounded samples of the same workload, host cores of this box:
+    N in {4096, 8192, 16384}, least-squares fit t = a N^2 + b N^3, labelled extrapolation to N_bench."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     from nngp_src_amd import synth
+    lapack = None
+    try:  # second opinion on the dominant stage, timed BEFORE the OpenMP oracle spins up its threads:
+        import scipy.linalg  # LAPACK dpotrf through SciPy on an SPD matrix (BASELINE.md section 2)
+        nl = 6144
+        g = np.random.default_rng(0).standard_normal((nl, 256))
+        a = g @ g.T / 256 + np.eye(nl)
+        t0 = time.perf_counter()
+        scipy.linalg.cho_factor(a, lower=True, overwrite_a=True, check_finite=False)
+        tl = time.perf_counter() - t0
+        lapack = {"ms": round(tl * 1e3, 1), "gflops": round((nl ** 3 / 3) / tl / 1e9, 1),
+                  "note": "scipy.linalg.cho_factor float64 on a random SPD matrix, N=%d" % nl}
+        del a, g
+    except Exception as e:  # pragma: no cover
+        lapack = {"error": str(e)}
     c_oracle.set_threads(min(16, os.cpu_count() or 1))  # the GPU box gives one GPU a 16-core CPU share
-    x, y = synth.synthetic_queries(n, d, seed=0)
-    xt, _ = synth.synthetic_queries(m, d, seed=1)
     w, b = [1.0] * (n_relu + 1), [0.0] * (n_relu + 1)
-    c_oracle.kernel_build(x[:256], None, "nngp", w, b)  # warm the thread pool
-    t0 = time.perf_counter()
-    model = c_oracle.fit(x, y, w, b, get="nngp")
-    c_oracle.predict_nngp(model, xt, 1)
-    dt = time.perf_counter() - t0
-    fl = flop_model(n, d, m, n_relu)
-    out = {"value": round(fl["total"] / dt / 1e9, 3), "unit": "GFLOP/s", "cores": c_oracle.num_threads(), "kind": "port",
-           "sample": "same step at N=%d, d=%d, M=%d, n_relu=%d, float64 C/OpenMP oracle: %.2f s (build %.2f, potrf %.2f)"
-                     % (n, d, m, n_relu, dt, model["stage_sec"][0], model["stage_sec"][1]),
-           "ms": round(dt * 1e3, 1)}
-    out["lapack_dpotrf"] = lapack
+    sizes = [int(v) for v in os.environ.get("NNGP_CPU_SIZES", "4096,8192,16384").split(",")]
+    mm = min(m, 256)
+    xt, _ = synth.synthetic_queries(mm, d, seed=1)
+    c_oracle.kernel_build(xt, None, "nngp", w, b)  # warm the thread pool
+    samples = []
+    for n in sizes:
+        x, y = synth.synthetic_queries(n, d, seed=0)
+        t0 = time.perf_counter()
+        model = c_oracle.fit(x, y, w, b, get="nngp")
+        c_oracle.predict_nngp(model, xt, 1)
+        dt = time.perf_counter() - t0
+        fl = flop_model(n, d, mm, n_relu)
+        samples.append({"N": n, "M": mm, "sec": round(dt, 3), "build_sec": round(float(model["stage_sec"][0]), 3),
+                        "potrf_sec": round(float(model["stage_sec"][1]), 3), "gflops": round(fl["total"] / dt / 1e9, 2)})
+        del model, x, y
+    ns = np.array([s["N"] for s in samples], dtype=np.float64)
+    ts = np.array([s["sec"] for s in samples])
+    coef, *_ = np.linalg.lstsq(np.stack([ns ** 2, ns ** 3], axis=1), ts, rcond=None)
+    t_bench = float(coef[0] * n_bench ** 2 + coef[1] * n_bench ** 3)
+    big = samples[-1]
+    out = {"value": big["gflops"], "unit": "GFLOP/s", "cores": c_oracle.num_threads(), "kind": "port",
+           "sample": "same step (kernel build + float64 Cholesky + alpha + posterior for M=%d) by the float64 C/OpenMP oracle at "
+                     "N = %s, d=%d, n_relu=%d; `value` is the largest sample" % (mm, sizes, d, n_relu),
+           "samples": samples,
+           "extrapolation": {"model": "t = a N^2 + b N^3 (least squares over the samples)", "a": float(coef[0]), "b": float(coef[1]),
+                             "N": n_bench, "cpu_sec_extrapolated": round(t_bench, 2),
+                             "gpu_ms_per_step": round(gpu_ms, 3),
+                             "speedup_vs_extrapolated_cpu": round(t_bench * 1e3 / gpu_ms, 1),
+                             "note": "EXTRAPOLATED, not measured at N=%d; M differs (CPU %d, GPU %d test queries)" % (n_bench, mm, m)},
+           "lapack_dpotrf": lapack}
     return out
 
 
@@ -88,18 +111,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg3 on one GPU, cfg4 on several")
+    ap.add_argument("--mode", default=os.environ.get("NNGP_DIST_MODE", "shard"), choices=["shard", "replicate"],
+                    help="multi-GPU layout (default: the north star's row-block shard + all-gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-compare", action="store_true", help="multi-GPU: skip the untimed comparison legs")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from nngp_src_amd import distributed, synth
+    from nngp_src_amd import _lib, distributed, synth
     from nngp_src_amd.model import GPModel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         # NNGP_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
@@ -114,14 +141,15 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    cfg_name = args.config or ("cfg3" if world == 1 else "cfg4")
 
     knobs = bool(os.environ.get("NNGP_DEBUG"))
     if knobs:  # timing experiments only (scripts/gpu_ab.sh), e.g. NNGP_DEBUG="2=1" disables the look-ahead Cholesky: runs on
-        from nngp_src_amd import _lib  # libnngp_hip_knobs.so -- the product library has no such switches
-        for kv in os.environ["NNGP_DEBUG"].split(","):
+        for kv in os.environ["NNGP_DEBUG"].split(","):  # libnngp_hip_knobs.so -- the product library has no such switches
             k, v = kv.split("=")
             _lib.load(knobs=True).nngp_debug_set(int(k), int(v))
-    n, d, n_relu, get, m, join_block, desc = CONFIGS[args.config]
+    n, d, n_relu, get, m, join_block, desc = CONFIGS[cfg_name]
     x, y = synth.synthetic_queries(n, d, seed=0, join_block=join_block)
     xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
     xd, yd, xtd = (torch.from_numpy(a).to(dev) for a in (x, y, xt))
@@ -132,26 +160,42 @@ def main():
     model = GPModel(n_cap, d, w_std, b_std, get=get, diag_reg=1e-3, m_cap=max(m1 - m0, 1), knobs=knobs)
     if os.environ.get("NNGP_REFINE"):  # covariance precision level (default: the library's)
         model.set_refine(int(os.environ["NNGP_REFINE"]))
-    cov = "diag" if get == "nngp" else False
-    shard = world > 1 and os.environ.get("NNGP_DIST_MODE", "replicate") == "shard"
+    cov = "diag"  # the reference asks for the covariance and consumes its diagonal (train.py:157-158,180), for nngp and ntk
+    shard = world > 1 and args.mode == "shard"
+    dist_chol = os.environ.get("NNGP_DIST_CHOL", "1") != "0"
+
+    # the shard's one data-path collective: the library's own RCCL communicator (C ABI), torch.distributed otherwise
+    comm, collective = None, None
+    if shard:
+        collective = "torch.distributed %s all_gather_into_tensor (in place)" % backend
+        if backend == "nccl" and os.environ.get("NNGP_COLLECTIVE", "native") == "native":
+            try:
+                comm = distributed.NativeComm()
+                collective = "libnngp_hip nngp_allgather_rows: ncclAllGather in place (%s)" % comm.library
+            except _lib.NngpError as e:  # every rank fails alike (same library, same box); recorded in the line
+                collective += " [native RCCL communicator unavailable: %s]" % str(e)[:120]
+            flag = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm = None
 
     def ev():
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         return e
 
-    def step(stages=None):
+    def step(stages=None, sharded=shard):
         e0 = ev()
         model.set_train(xd, yd)
         e1 = ev()
         r0, r1 = distributed.row_partition(n, world, rank)
-        model.build_rows(r0, r1) if shard else model.build_rows(0, n)
+        model.build_rows(r0, r1) if sharded else model.build_rows(0, n)
         e2 = ev()
-        if shard:
+        if sharded:
             buf, _ = model.kernel_buffer(all_rows=True)
-            distributed.allgather_rows(buf, n)
+            distributed.allgather_rows(buf, n, comm=comm)
         e3 = ev()
-        if shard and os.environ.get("NNGP_DIST_CHOL", "1") != "0":
+        if sharded and dist_chol:
             distributed.distributed_factor(model)  # block columns dealt cyclically, one broadcast per column
         else:
             model.factor()
@@ -172,6 +216,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(values):
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -181,22 +232,57 @@ def main():
         step(stages)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    (elapsed,) = max_over_ranks([elapsed])
 
     info = model.info()
+    alpha_l2 = float(torch.linalg.vector_norm(model.alpha()).item())
+    names = sorted(stages)
+    st = dict(zip(names, max_over_ranks([float(np.mean(stages[k])) for k in names])))  # slowest rank per stage
+
+    # ---- comparison legs, after the timed region (multi-GPU): full build on every rank, and the replicate layout ----
+    shard_report = None
+    if world > 1 and shard:
+        chunk = distributed.row_chunk(n, world)
+        ld = model.kernel_buffer()[1]
+        recv_bytes = (world - 1) * chunk * ld * 8
+        shard_report = {"sharded_build_ms": round(st["kernel_build"], 3), "allgather_ms": round(st["allgather"], 3),
+                        "allgather_GB_received_per_rank": round(recv_bytes / 1e9, 3),
+                        "allgather_GBps_per_rank": round(recv_bytes / 1e9 / (st["allgather"] * 1e-3), 1) if st["allgather"] > 0 else None,
+                        "replicated_full_build_ms": None, "replicate_layout_ms_per_step": None,
+                        "ranks_seen": ranks_seen, "collective": collective,
+                        "cholesky": "1-D block-cyclic, one broadcast per 1024-wide block column" if dist_chol else "replicated on every rank"}
+        if not args.no_compare:
+            model.set_train(xd, yd)
+            ts = []
+            for _ in range(3):
+                barrier()
+                a_ = ev(); model.build_rows(0, n); b_ = ev()
+                torch.cuda.synchronize()
+                ts.append(a_.elapsed_time(b_))
+            (full_ms,) = max_over_ranks([min(ts)])
+            shard_report["replicated_full_build_ms"] = round(full_ms, 3)
+            step(sharded=False)
+            barrier()
+            tr = time.perf_counter()
+            for _ in range(2):
+                step(sharded=False)
+            barrier()
+            (rep,) = max_over_ranks([(time.perf_counter() - tr) / 2 * 1e3])
+            shard_report["replicate_layout_ms_per_step"] = round(rep, 3)
+
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg_name)
     if os.path.exists(tpath):  # HBM bytes of the Cholesky kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
         traffic = json.load(open(tpath)).get("cholesky_bytes")
-        traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % args.config
+        traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
     if rank == 0:
         fl = flop_model(n, d, m, n_relu)
         ms = elapsed / args.steps * 1e3
-        st = {k: float(np.mean(v)) for k, v in stages.items()}
         chol_tflops = fl["cholesky"] / (st["cholesky"] * 1e-3) / 1e12
+        post_ms = st["posterior"] + st["alpha_solve"]
+        post_tflops = fl["posterior"] / (post_ms * 1e-3) / 1e12
+        k_bytes = (8 * n * n + 8 * n * d) * (1 if world == 1 or not shard else 1.0 / world)
+        k_gbps = k_bytes / (st["kernel_build"] * 1e-3) / 1e9
         result = {
             "metric": "NNGP kernel-build + GP-solve wall-clock (ms) and GFLOP/s at N train queries",
             "value": round(fl["total"] / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s",
@@ -205,11 +291,12 @@ def main():
             "dtype": "f32 (Cholesky products as split f16 x3, f32 accumulate; f64 build/CG/means)", "data": "synthetic",
             "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": m,
                        "parallelism": ("single GPU" if world == 1 else
-                                       ("row-block kernel shard x%d + all-gather, block-cyclic Cholesky (broadcast per block column), "
-                                        "replicated solve, test rows sharded" % world) if shard else
+                                       ("row-block kernel shard x%d + one in-place all-gather, %s, replicated alpha solve, test rows sharded"
+                                        % (world, "block-cyclic Cholesky (broadcast per block column)" if dist_chol else "replicated Cholesky")) if shard else
                                        "fit replicated on %d GPUs (no data-path collective), test rows sharded" % world),
                        "precision": "float64 kernel build + CG residual; float32 Cholesky (preconditioner) whose trailing updates run "
-                                    "as split-float16 MFMA products (hi+lo, 3 per term, float32 accumulate); float64 means"},
+                                    "as split-float16 MFMA products (hi+lo, 3 per term, float32 accumulate); float64 means; variances: "
+                                    "float32 solves + one float64 residual product (level 1)"},
             # Cholesky stage = the dominant cost.  `achieved` = algorithmic F_C / stage time.  Its matrix work runs on the
             # float16 pipe at 3 products per float32-grade term, so the hardware peak for it is PEAK_F16 / 3; the
             # fraction of the float32-MFMA roofline the north star names is reported beside it (it can exceed 1).
@@ -224,18 +311,34 @@ def main():
                          "frac_of_f32_mfma_peak": round(chol_tflops / PEAK_F32_MFMA_TFLOPS, 4),
                          "north_star_frac_build_plus_cholesky": round((fl["kernel_build"] + fl["cholesky"]) /
                                                                        ((st["kernel_build"] + st["cholesky"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            # the other two stages against the rooflines SURVEY.md 8d names for them
+            "roofline_posterior": {"bound": "mfma", "achieved": round(post_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(post_tflops / PEAK_F32_MFMA_TFLOPS, 4), "stage_ms": round(post_ms, 3),
+                                   "work": "2NMd + 4NM + N^2 M (cross kernel, mean, variances) for this rank's %d test rows x world" % (m1 - m0)
+                                           if world > 1 else "2NMd + 4NM + N^2 M (cross kernel, mean, variances)",
+                                   "note": "algorithmic count; executed: one float64 MFMA product 2 N^2 M (78.6 TF/s pipe), three float32-grade "
+                                           "triangular solves N^2 M each on the float16 pipe, the alpha CG on HBM"},
+            "roofline_k1": {"bound": "hbm", "achieved": round(k_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                            "frac": round(k_gbps / PEAK_HBM_GBPS, 4), "stage_ms": round(st["kernel_build"], 3),
+                            "bytes": "8 N^2 + 8 N d (float64 K written once, X read once)" + ("" if world == 1 or not shard else " / world")},
             "stages_ms": {k: round(v, 3) for k, v in st.items()},
             "stages_note": "the CG solve for alpha is deferred to the posterior stage, where it runs on its own stream under the "
                            "covariance products (alpha_solve only records the request); with a covariance it stops at 1e-6 and "
                            "the mean is corrected through the covariance rows (mu = K_td a_k + Z r_k, ~1e-9 of the converged "
-                           "mean); fit_info is read after the timed steps, where info() runs the solve on to 1e-10",
+                           "mean); fit_info is read after the timed steps, where info() runs the solve on to 1e-10"
+                           + ("; stages are the slowest rank's" if world > 1 else ""),
             "fit_info": {"cg_iters": info["refine_iters"], "rel_residual": info["rel_residual"],
-                         "clamped_pivots": info["clamped_pivots"], "reg": info["reg"],
-                         "alpha_l2": float(torch.linalg.vector_norm(model.alpha()).item())},
+                         "clamped_pivots": info["clamped_pivots"], "reg": info["reg"], "alpha_l2": alpha_l2},
         }
+        if shard_report is not None:
+            result["shard"] = shard_report
+        elif world > 1:
+            result["shard"] = {"ranks_seen": ranks_seen, "note": "replicate layout: no data-path collective"}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(n_relu, get)
+            result["cpu_baseline"] = cpu_baseline(n, d, m, n_relu, ms)
         print(json.dumps(result), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -159,12 +159,14 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  * of blocked triangular solves and shrinks the error by rho ~ 2e-2 (N = 32768).
  * (max relative error of diag(cov) measured at N = 32768, d = 128, M = 1024; profiles/r1o_var_study.json):
  *   0      float32 only, cov = K_tt - V^T V                                                        1e-2
- *   1      diag: z0.(k + r0) + r0.d with r0 = k - A z0, d = M^-1 r0 (one float64 product)           2e-6
- *          full covariance: one sweep, cov = K_tt - sym(Z K_dt)                                     1e-3
- *   2      one sweep + the second-order formula sym(z_i . (k_j + r_j)) (default; the diagonal       4e-7
- *          through the quadratic form z^T A z on the lower triangle of K: 1.5 products)
+ *   1      (default) diag: z0.(k + r0) + |L^-1 r0|^2 with r0 = k - A z0: ONE float64 product, a solve pair for    2e-6
+ *          z0 and a forward solve for the remainder e0^T A e0 = r0^T A^-1 r0 ~ r0^T M^-1 r0 (the exact identity
+ *          k^T A^-1 k = z0.(k + r0) + e0^T A e0 holds for whatever z0 the float32 solves return);
+ *          full covariance and the NTK covariance run at level 2
+ *   2      one sweep + the second-order formula sym(z_i . (k_j + r_j)) (the diagonal through the quadratic form    4e-7
+ *          z^T A z on the lower triangle of K: 1.5 products)
  *   L > 2  L-1 sweeps + the second-order formula                                     2e-10 at L = 3
- * Levels >= 2 are adaptive: the sweeps contract by the spectral radius of I - M^-1 A (M = the float32 factor), which
+ * Levels >= 1 are adaptive: the sweeps contract by the spectral radius of I - M^-1 A (M = the float32 factor), which
  * approaches 1 when cond(K + reg I) * eps32 does (small diag_reg, low-dimensional encodings).  After the fixed sweeps
  * predict checks two signs of that -- the alpha solve took >= 8 CG iterations (NTK: >= 4), or a row's first-order term
  * z.r is too large for its second-order error to be small (a loose lower bound: the backstop when the alpha solve says

@@ -91,7 +91,7 @@ struct nngp_model {
     float* vvt32 = nullptr;      // [fullp, fullp]
 
     // float64 refinement of the posterior covariance (grown on demand)
-    int var_refine = 2;          // covariance precision level, see nngp_model_set_refine
+    int var_refine = 1;          // covariance precision level, see nngp_model_set_refine
     float* lt32 = nullptr;       // [np_cap, np_cap] L^T, built lazily after a fit
     float* dinvt = nullptr;      // transposed inverted 128-blocks
     bool lt_ready = false;
@@ -991,7 +991,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // The covariance does not depend on alpha: it is enqueued first, then the deferred CG solve runs on its own stream
     // (overlapping it), and the mean follows once alpha is there.
     // Levels >= 2 check afterwards whether the fixed number of correction sweeps was enough (cov_adaptive below):
-    // 0 nothing to check, 1 NNGP diag, 2 NNGP full, 3 NTK.
+    // 0 nothing to check, 1 NNGP diag, 2 NNGP full, 3 NTK, 4 NNGP diag at level 1.
     int check_kind = 0;
     bool z_valid = false;  // z64 ends up holding the rows K_td (K + reg I)^-1 (to first order): the mean can be corrected through them
     const bool full = (cov_mode == NNGP_COV_FULL);
@@ -1057,22 +1057,26 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         // NNGP: cov_ij = K_tt,ij - k_i^T A^-1 k_j with Z ~ K_td A^-1 (float32 solve + float64 correction sweeps).
         //   level 1: one sweep, cov = K_tt - sym(Z K_dt)  (error ~ rho * float32 error); diag only: see below
         //   level L >= 2: L-1 sweeps, then with R = K_td - Z A:  k_i^T A^-1 k_j = sym(z_i . (k_j + r_j)) + O(err^2)
-        const int level = (serving && m->var_refine < 2) ? 2 : m->var_refine;  // the inverse needs the second-order formula
-        const bool second_order = level >= 2 || (!full && level == 1);
-        if (!full && level == 1 && NNGP_KNOB(5) == 1) {
-            // diag, one float64 product: with z0 from the float32 factor, r0 = k - A z0 and d = M^-1 r0,
-            //   k^T A^-1 k = z0.(k + r0) + e0^T A e0  and  e0^T A e0 = r0^T A^-1 r0 ~ r0.d   (error: rho e0^T A e0;
-            // 70x better than the first-order formula at z0 + d for the same work: 2e-5 instead of 1.4e-3 at N = 32768)
-            NNGP_TRY(launch_convert_f64_f32(ktd, np, m->b32, np, mp, np, mp, np, s));
-            NNGP_TRY(apply_inverse_f32(m, mp, s));
-            NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));
-            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
-            NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));  // r0
+        // the explicit inverse needs the second-order formula; the full covariance has no cheap remainder estimate: level >= 2
+        const int level = ((serving || (full && m->var_refine == 1)) && m->var_refine < 2) ? 2 : m->var_refine;
+        const bool second_order = level >= 2;
+        if (!full && level == 1) {
+            // diag, ONE float64 product and three triangular solves (the default).  With z0 = M^-1 k from the float32 factor
+            // M = L L^T and r0 = k - A z0:   k^T A^-1 k = z0.(k + r0) + e0^T A e0   exactly, for whatever z0 the solves
+            // returned, and   e0^T A e0 = r0^T A^-1 r0 ~ r0^T M^-1 r0 = |L^-1 r0|^2   -- a forward solve only, and only the
+            // correction term (<~ 1e-2 of the variance) depends on it.  Measured at N = 32768 against level 4: 2.1e-6 worst
+            // relative error (level 2: 4.2e-7 for one more solve pair and half a float64 product; the formula without the
+            // last term, z0.(k + r0) via the quadratic form alone: 4.7e-3 -- e0^T A e0 is NOT negligible).
+            NNGP_TRY(solve_rows(0, true));
+            z_valid = true;
             NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
+            NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s));
             NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
-            NNGP_TRY(apply_inverse_f32(m, mp, s));
-            NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));  // d
-            return launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, var_or_cov, -1.0, var_or_cov, s);
+            NNGP_TRY(apply_forward_f32(m, mp, s));
+            NNGP_TRY(launch_row_sqsum_f32(m->b32, np, mt, np, var_or_cov, var_or_cov, s));
+            check_kind = 4;  // like 1, and r64 already holds the residual of z64
+            return launch_rows_prepare(m->rows.delta, m->tt_diag, var_or_cov, nullptr, 0, kFlagThr, mt, m->rows.tol,
+                                       m->rows.live + 1, s);
         }
         if (!full && serving && mt <= (np <= 16384 ? 32 : 16) && !m->serving_weak) {
             z_valid = true;
@@ -1156,7 +1160,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     ntk_cross = ktd_n;
     z_valid = true;
     if (full) NNGP_TRY(build_ktt());
-    if (m->var_refine >= 2) check_kind = 3;
+    if (m->var_refine >= 1) check_kind = 3;
     return ntk_finish();
     };
     if (cov_mode != NNGP_COV_NONE) NNGP_TRY(cov_part());
@@ -1181,6 +1185,8 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         if (weak) {
             if (check_kind == 2) {
                 NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, -1.0, np, mp, np, s));  // back from G = K_td + R to R
+            } else if (check_kind == 4) {
+                // level 1: r64 is the residual of z64 already
             } else {
                 NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
                 NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));

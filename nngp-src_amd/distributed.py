@@ -35,12 +35,69 @@ def row_partition(n: int, world: int, r: int):
     return min(r * c, n), min((r + 1) * c, n)
 
 
-def allgather_rows(buf, n: int, group=None):
-    """All-gather the row blocks of ``buf`` ([rows >= world*chunk, ld] torch tensor) in place.
+class NativeComm:
+    """RCCL communicator owned by libnngp_hip.so (``nngp_comm_*``, include/nngp_hip.h section e).
+
+    ``torch.distributed`` only carries the 128-byte unique id from rank 0 to the others; the all-gather itself is the
+    library's ``nngp_allgather_rows`` (ncclAllGather, in place) on the caller's HIP stream.  One rank per GPU -- RCCL
+    refuses two ranks on one device, so the gloo rehearsals on a single GPU cannot use it."""
+
+    def __init__(self, group=None):
+        import ctypes
+        import torch
+        from . import _lib
+        dist = _dist()
+        self.lib = _lib.load()
+        self.world, self.rank = world_size(), rank()
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(self.lib.nngp_comm_unique_id(ident), self.lib)
+        if self.world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0, group=group)
+            ident = ctypes.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.nngp_comm_create(ctypes.byref(self.handle), ident, self.world, self.rank), self.lib)
+        self.library = (self.lib.nngp_comm_library() or b"").decode()
+
+    def allgather_rows(self, buf, n: int):
+        from . import _lib
+        import torch
+        if not buf.is_contiguous() or buf.shape[0] < self.world * row_chunk(n, self.world):
+            raise ValueError("all-gather buffer must be contiguous with >= world * chunk rows")
+        dt = {torch.float64: _lib.DTYPE_F64, torch.float32: _lib.DTYPE_F32}[buf.dtype]
+        _lib.check(self.lib.nngp_allgather_rows(_lib.ptr(buf), int(n), int(buf.stride(0)), dt, self.handle, _lib.stream_ptr()),
+                   self.lib)
+        return buf
+
+    def bcast(self, t, root: int):
+        from . import _lib
+        import torch
+        dt = {torch.float64: _lib.DTYPE_F64, torch.float32: _lib.DTYPE_F32}[t.dtype]
+        _lib.check(self.lib.nngp_bcast(_lib.ptr(t), t.numel(), dt, int(root), self.handle, _lib.stream_ptr()), self.lib)
+        return t
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nngp_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allgather_rows(buf, n: int, group=None, comm: "NativeComm" = None):
+    """All-gather the row blocks of ``buf`` ([rows >= world*chunk, ld] torch tensor) IN PLACE.
 
     Every rank must have written its own rows ``row_partition(n, world, rank)``; on return rows [0, n) are
     complete on every rank.  Sends exactly chunk*ld elements per rank (the short tail block is padded by
-    whatever the buffer holds -- rows >= n are never read).
+    whatever the buffer holds -- rows >= n are never read); the send block is the rank's own slice of the receive
+    buffer, so nothing is copied.  ``comm``: the library's own RCCL communicator (``NativeComm``); otherwise
+    ``torch.distributed`` (nccl = RCCL on ROCm; gloo in the rehearsals, staged through the host).
     """
     import torch
     dist = _dist()
@@ -50,21 +107,25 @@ def allgather_rows(buf, n: int, group=None):
     c = row_chunk(n, world)
     if buf.shape[0] < world * c:
         raise ValueError("all-gather buffer has %d rows, needs %d" % (buf.shape[0], world * c))
-    mine = buf[r * c:(r + 1) * c].contiguous().clone()
+    if comm is not None:
+        return comm.allgather_rows(buf, n)
     out = buf[: world * c]
+    mine = out[r * c:(r + 1) * c]
     if buf.is_cuda and dist.get_backend(group) != "nccl":
-        # rehearsal path (gloo with device buffers): stage through the host, chunk by chunk to bound host memory
+        # rehearsal path (gloo with device buffers): stage through the host
         host = mine.cpu()
         parts = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(parts, host, group=group)
         for g, p in enumerate(parts):
             if g != r:
                 out[g * c:(g + 1) * c].copy_(p)
+    elif out.is_contiguous() and dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)  # in place: send = own slice of recv
     elif out.is_contiguous():
-        dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
+        dist.all_gather_into_tensor(out.view(-1), mine.reshape(-1).clone(), group=group)  # gloo: no aliasing
     else:  # pragma: no cover
         parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
+        dist.all_gather(parts, mine.contiguous(), group=group)
         for g, p in enumerate(parts):
             out[g * c:(g + 1) * c].copy_(p)
     return buf
@@ -198,7 +259,7 @@ def _any_rank(flag: bool, group=None) -> bool:
     return bool(int(t.item()))
 
 
-def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True):
+def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True, comm=None):
     """GPModel fit with the kernel build sharded over ranks: build own rows -> all-gather -> replicated
     factor + solve.  The model must have been created with n_cap >= world * ceil(n / world)."""
     import torch
@@ -215,7 +276,7 @@ def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True
     t1 = ev()
     if world > 1:
         buf, _ = model.kernel_buffer(all_rows=True)
-        allgather_rows(buf, n, group)
+        allgather_rows(buf, n, group, comm)
     t2 = ev()
     if world > 1 and distributed_cholesky:
         distributed_factor(model, group)

@@ -121,9 +121,10 @@ class GPModel:
         self._check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 
     def set_refine(self, sweeps: int):
-        """Precision level of the posterior covariance: 0 = float32 solve only; 1 = one float64 residual, second-order
-        formula at the float32 solution plus its preconditioned remainder (diag; full covariance: one sweep);
-        L >= 2 = L-1 correction sweeps plus the second-order formula (default 2)."""
+        """Precision level of the posterior covariance.  0 = float32 solve only (~1e-2 at N = 32768); 1 (default) = one
+        float64 residual: second-order formula at the float32 solution plus the preconditioned estimate of its remainder
+        (diag: ~2e-6 at N = 32768; full covariance and NTK run at level 2); L >= 2 = L-1 correction sweeps plus the
+        second-order formula.  Levels >= 1 continue by per-row CG when the float32 factor is a weak preconditioner."""
         self._check(self.lib.nngp_model_set_refine(self.handle, int(sweeps)))
         return self
 

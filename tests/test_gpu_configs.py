@@ -9,7 +9,7 @@ independent of the GPU's own kernel matrix and factor:
 * alpha: ``K_oracle[rows] alpha + reg alpha[rows] = y[rows]`` on a sample of rows, with ``reg`` recomputed from the
   oracle's diagonal;
 * posterior mean of ALL M test queries against ``K_oracle(x_test, X) alpha``;
-* posterior variance, level 2 (default) against level 3 on a 64-query subset, and INDEPENDENTLY for a few queries c:
+* posterior variance, default level (1) against level 3 on a 64-query subset, and INDEPENDENTLY for a few queries c:
   a second fit with y := k_c (ny = 4 columns) gives candidate solutions z_c = A^-1 k_c; the oracle streams the
   whole N x N kernel once (rows in blocks, never stored), forms A z_c in float64, and then
   ``k^T A^-1 k = 2 z.k - z^T A z`` up to ``r^T A^-1 r <= |r|^2 / reg`` with r = k - A z -- a bound the CPU evaluates
@@ -81,7 +81,17 @@ def test_baseline_config_at_full_size(name):
     # kernel buffer: rows against the oracle, symmetry of corner blocks
     kbuf, _ = model.kernel_buffer()
     rows8 = np.array([0, 1, 127, 128, n // 2 + 3, n - 130, n - 2, n - 1])
-    np.testing.assert_allclose(kbuf[rows8, :n].cpu().numpy(), _oracle_rows(x[rows8], x, get, a), rtol=1e-11, atol=0)
+    got, ref = kbuf[rows8, :n].cpu().numpy(), _oracle_rows(x[rows8], x, get, a)
+    rel = np.abs(got - ref) / np.abs(ref)
+    bad = np.argwhere(rel > 1e-11)
+    # The NTK is first-order sensitive to s = sqrt(q q' - k^2) (Theta ~ k (pi - atan2(s, k)) / 2 pi), and for numerically
+    # PARALLEL rows q q' - k^2 is pure rounding noise of size eps q q' in any float64 evaluation -- the oracle's as much
+    # as the GPU's (or XLA's): such entries agree to sqrt(eps) / 2 pi only.  Everything else must meet 1e-11.
+    for r, c in bad:
+        xi, xj = x[rows8[r]], x[c]
+        cos = float(xi @ xj) / float(np.sqrt((xi @ xi) * (xj @ xj)))
+        assert get == "ntk" and 1.0 - cos < 1e-12 and rel[r, c] < 1e-8, (rows8[r], c, cos, rel[r, c])
+    assert len(bad) <= 8, len(bad)
     for r0, c0 in ((0, 0), (n - 512, 0), (n - 512, n - 512), (n // 2 - 100, n // 3)):
         blk, blk_t = kbuf[r0:r0 + 512, c0:c0 + 512].cpu().numpy(), kbuf[c0:c0 + 512, r0:r0 + 512].cpu().numpy()
         assert np.array_equal(blk, blk_t.T)
@@ -107,7 +117,7 @@ def test_baseline_config_at_full_size(name):
     sub = np.arange(0, m, m // 64)[:64]
     model.set_refine(3)
     _, var3 = model.predict(xt[sub], cov="diag")
-    model.set_refine(2)
+    model.set_refine(1)
     assert np.all(var3 > 0)
     lvl = float(np.max(np.abs(var[sub] - var3) / var3))
     assert lvl < (1e-4 if get == "nngp" else 1e-3), lvl  # SURVEY 8d gate: 1e-3

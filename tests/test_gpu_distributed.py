@@ -87,3 +87,25 @@ def test_two_rank_fit_survives_a_float32_breakdown(tmp_path):
         g = np.load(tmp_path / ("rank%d.npz" % r))
         assert np.linalg.norm(g["mean"] - m0) / np.linalg.norm(m0) < 1e-7
         np.testing.assert_allclose(g["var"], v0, rtol=1e-5)
+
+
+def test_native_rccl_communicator_single_rank():
+    """The section-e entry points of the C ABI on the one GPU of the test box: librccl is found and bound at run time,
+    a one-rank communicator is created from a unique id, and the in-place all-gather / broadcast run on the caller's
+    stream and leave the data as it is (world = 1: every row block is the rank's own).  Two ranks cannot share a
+    device under RCCL, so the multi-rank exchange itself is covered by the gloo tests above and the driver's 8-GPU run."""
+    sys.path.insert(0, ROOT)
+    from nngp_src_amd import distributed, _lib
+    torch.cuda.set_device(0)
+    comm = distributed.NativeComm()
+    assert comm.world == 1 and comm.rank == 0 and "rccl" in comm.library.lower() or comm.library.startswith("symbols"), comm.library
+    k = torch.arange(6 * 8, dtype=torch.float64, device="cuda").reshape(6, 8).contiguous()
+    before = k.clone()
+    comm.allgather_rows(k, 5)
+    v = torch.arange(33, dtype=torch.float32, device="cuda")
+    comm.bcast(v, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(k, before) and torch.equal(v, torch.arange(33, dtype=torch.float32, device="cuda"))
+    lib = _lib.load()
+    assert lib.nngp_bcast(_lib.ptr(v), 33, _lib.DTYPE_F32, 3, comm.handle, None) != 0  # root outside the communicator
+    comm.close()
