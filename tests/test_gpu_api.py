@@ -179,7 +179,11 @@ def test_append_rows_matches_full_refit(n0, b, ncap):
         m_inc, v_inc = inc.predict(xt, cov="diag")
         m_ref, v_ref = ref.predict(xt, cov="diag")
         assert np.allclose(m_inc, m_ref, rtol=1e-8, atol=1e-8 * np.abs(m_ref).max())
-        assert np.allclose(v_inc, v_ref, rtol=1e-5, atol=1e-9 * np.abs(v_ref).max())
+        # default level 1; the extended factor is a weaker preconditioner (its old part belongs to the previous regulariser)
+        assert np.allclose(v_inc, v_ref, rtol=1e-4, atol=1e-9 * np.abs(v_ref).max())
+        _, v_inc2 = inc.set_refine(2).predict(xt, cov="diag")
+        inc.set_refine(1)
+        assert np.allclose(v_inc2, v_ref, rtol=1e-5, atol=1e-9 * np.abs(v_ref).max())
         # the train-train kernel in HBM is the full symmetric matrix of the concatenated set
         k_inc, ld = inc.kernel_buffer()
         k_ref, ld_ref = ref.kernel_buffer()

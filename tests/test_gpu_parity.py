@@ -345,7 +345,7 @@ def test_fit_predict_nngp(n, m, d, n_relu):
     np.testing.assert_allclose(mean2, mean, rtol=1e-6, atol=1e-6 * np.abs(mean).max())  # corrected through different rows Z
     assert np.abs(cov - cov_ref).max() < 1e-6 * np.abs(np.diag(cov_ref)).max()
     assert np.array_equal(cov, cov.T)
-    np.testing.assert_allclose(np.diag(cov), var, rtol=1e-9)
+    np.testing.assert_allclose(np.diag(cov), var, rtol=1e-6)  # full covariance: level 2; diag: level 1 (the default)
     model.set_refine(3)  # two sweeps + second-order formula
     var3 = model.predict(xt, cov="diag")[1]
     _, cov3 = model.predict(xt, cov="full")
@@ -676,7 +676,7 @@ def test_random_sweep_against_the_float64_oracle(seed):
     shift = model.factor_shift() / info["reg"]
     _, cov = model.predict(xt[:64], cov="full")
     prior = o.diag_kernel(np.sum(xt * xt, axis=1) / c["d"], a)[0].max()  # var = prior - ...: resolution eps64 * prior
-    assert np.abs(np.diag(cov) - var[:64]).max() <= 1e-5 * np.abs(var[:64]).max() + 1e-13 * prior
+    assert np.abs(np.diag(cov) - var[:64]).max() <= 1e-4 * np.abs(var[:64]).max() + 1e-13 * prior  # level 2 vs level 1
     if c["get"] == "nngp":
         ref = c_oracle.fit(x, y, a.w_std, a.b_std, diag_reg=c["diag_reg"], absolute=c["absolute"])
         mean_ref, var_ref = c_oracle.predict_nngp(ref, xt, 1)

@@ -151,3 +151,65 @@ def test_golden_forest_fixture_reproduces(golden_dir):
     mc, vc = c_oracle.predict_nngp(model, g["X_test"], 1)
     np.testing.assert_allclose(mc, g["nngp_mean"], rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(vc, g["nngp_var"], rtol=1e-6)
+
+
+# ---- independent pins (tests/golden/oracle_pins.json, scripts/make_oracle_pins.py): nothing below was produced by the
+# ---- closed forms the oracle restates ----
+def _pins(golden_dir):
+    import json
+    return json.load(open(os.path.join(golden_dir, "oracle_pins.json")))
+
+
+def test_finite_width_networks_pin_nngp_and_ntk(golden_dir):
+    """Random ReLU networks of width 4096 in the NTK parameterisation of stax.Dense (train.py:161-164 widened to n_relu
+    hidden layers; W_std, b_std incl. bias): the mean over seeds of the Jacobian inner product (torch autograd) is the
+    empirical NTK, the mean of W_std^2 a.a'/width + b_std^2 the NNGP kernel.  The oracle's closed forms must lie within
+    4.5 standard errors (+ the O(1/width) finite-width bias) of both, entry by entry."""
+    for case in _pins(golden_dir)["finite_width"]:
+        x = np.array(case["x"])
+        a = o.make_arch(case["n_relu"], case["w_std"], case["b_std"])
+        for get in ("nngp", "ntk"):
+            K = o.kernel_fn(x, None, get, a)
+            mean, se = np.array(case[get + "_mean"]), np.array(case[get + "_stderr"])
+            bias = 3.0 / case["width"] * np.sqrt(np.outer(np.diag(K), np.diag(K)))
+            dev = np.abs(K - mean) / (4.5 * se + bias)
+            assert dev.max() < 1.0, (case["n_relu"], case["b_std"], get, dev.max())
+            # and the estimate is sharp enough to mean something: the typical standard error is ~1 % of the kernel's scale or better
+            assert np.median(se) < 0.02 * np.abs(K).max(), (get, np.median(se), np.abs(K).max())
+
+
+def test_gaussian_integral_definition_pins_the_closed_form(golden_dir):
+    """E[relu(u) relu(v)] and E[relu'(u) relu'(v)] by 40-digit quadrature of the Gaussian integrals that DEFINE a ReLU
+    layer (mpmath), chained through the layers with the NTK chain rule -- no arc-cosine formula involved.  The oracle
+    agrees to float64 rounding, for 1 and 3 hidden layers, with and without bias, and for W_std != 1."""
+    for case in _pins(golden_dir)["integral"]:
+        x = np.array(case["x"])
+        a = o.make_arch(case["n_relu"], case["w_std"], case["b_std"])
+        K, T = o.kernel_fn(x, None, "nngp", a), o.kernel_fn(x, None, "ntk", a)
+        scale_k, scale_t = np.abs(K).max(), np.abs(T).max()
+        for e in case["entries"]:
+            i, j = e["i"], e["j"]
+            assert abs(K[i, j] - float(e["nngp"])) <= 4e-15 * max(abs(float(e["nngp"])), 1e-3 * scale_k), (case["n_relu"], case["b_std"], e, K[i, j])
+            assert abs(T[i, j] - float(e["ntk"])) <= 4e-15 * max(abs(float(e["ntk"])), 1e-3 * scale_t), (case["n_relu"], case["b_std"], e, T[i, j])
+            # the C restatement too
+        Kc = c_oracle.kernel_build(x, None, "nngp", a.w_std, a.b_std)
+        Tc = c_oracle.kernel_build(x, None, "ntk", a.w_std, a.b_std)
+        for e in case["entries"]:
+            assert abs(Kc[e["i"], e["j"]] - float(e["nngp"])) <= 1e-13 * scale_k and abs(Tc[e["i"], e["j"]] - float(e["ntk"])) <= 1e-13 * scale_t
+
+
+def test_pin_generator_runs_live_at_small_width():
+    """The committed fixture's generator, run here at a size that takes seconds (width 512, 12 seeds; one integral entry):
+    looser, but shows the fixture is reproducible from scripts/make_oracle_pins.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_pins", os.path.join(os.path.dirname(__file__), "..", "scripts", "make_oracle_pins.py"))
+    P = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(P)
+    r = P.finite_width(P.X6, 2, 1.0, 0.3, 512, 12, seed0=5)
+    a = o.make_arch(2, 1.0, 0.3)
+    for get in ("nngp", "ntk"):
+        K = o.kernel_fn(P.X6, None, get, a)
+        mean, se = np.array(r[get + "_mean"]), np.array(r[get + "_stderr"])
+        assert (np.abs(K - mean) / (5 * se + 0.02 * np.abs(K).max())).max() < 1.0
+    g = P.integral_kernel(P.X4, 1, 1.0, 0.0, [(0, 1)], digits=30)
+    assert abs(float(g["entries"][0]["nngp"]) - 2.7204019972683966) < 1e-14 and abs(float(g["entries"][0]["ntk"]) - 4.5511008152653218) < 1e-14
