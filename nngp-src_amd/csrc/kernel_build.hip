@@ -12,6 +12,7 @@
 // Everything is float64: the GP solve behind this kernel has cond ~ 1e7, and a float32 Gram
 // perturbs posterior means by ~2.5e-4, over the 1e-4 parity gate.
 #include "common.h"
+#include "trig_tab.h"
 
 namespace nngp {
 
@@ -298,6 +299,273 @@ __global__ __launch_bounds__(256) void k_build(BuildArgs a, ArchDev arch, int64_
     }
 }
 
+// ---- float64 arithmetic of the ReLU map at ~1/3 of the libm cost (the epilogue is VALU-bound) --------------------------
+// 1 / x: v_rcp_f64 seed (>= 2^-26) + two Newton steps.  x > 0.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+// sqrt(r), r > 0: v_rsq_f64 seed, two coupled (Goldschmidt) iterations for g ~ sqrt(r), h ~ 1 / (2 sqrt(r)), and the residual
+// correction that makes the result faithful to the last bit or two.
+__device__ __forceinline__ double fast_sqrt_pos(double r) {
+    const double y = __builtin_amdgcn_rsq(r);
+    double g = r * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, r);
+    return fma(d, h, g);
+}
+
+// pi - atan2(s, k) for s >= 0 (what the ReLU map needs; s = k = 0 gives pi / 2, the reference's fill value).
+// A float32 estimate of the angle picks the nearest of 65 table angles a_i = i pi / 64; the pair (k, s) is rotated by -a_i in
+// float64, which leaves a residual angle below 0.03 rad whose arctangent is u - u^3/3 + ... + u^9/9 (next term < 2e-18).
+// tab[i] = {cos a_i, sin a_i, a_i, pi - a_i} in LDS.  Absolute error <= 5e-16 (checked against libm over 2e6 angles, radii
+// 1e-3 .. 1e6, and within 1e-12 of 0 and pi, in a NumPy emulation of these exact steps).
+__device__ __forceinline__ double pi_minus_atan2(double s, double k, const double* __restrict__ tab) {
+    const double ak = fabs(k);
+    const double mx = fmax(s, ak), mn = fmin(s, ak);
+    float t = mx > 0.0 ? (float)(mn * __builtin_amdgcn_rcp(mx)) : 0.0f;
+    float at = t * fmaf(-0.1919f, t * t, 0.9724f);  // atan on [0, 1] to 5e-3: only the table index depends on it
+    at = s > ak ? 1.57079637f - at : at;
+    at = k < 0.0 ? 3.14159274f - at : at;
+    int i = (int)rintf(at * 20.3718327f);  // 64 / pi
+    i = i < 0 ? 0 : (i > 64 ? 64 : i);
+    const double2 cs = *reinterpret_cast<const double2*>(tab + 4 * i);
+    const double xp = fma(k, cs.x, s * cs.y);      // rho cos(theta - a_i) > 0
+    const double yp = fma(s, cs.x, -(k * cs.y));   // rho sin(theta - a_i)
+    const double u = yp * fast_rcp(xp);
+    const double w = u * u;
+    double p = fma(w, 1.0 / 9.0, -1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0);
+    p = fma(p, w, -1.0 / 3.0);
+    const double atu = fma(u, p * w, u);
+    const double pmt = tab[4 * i + 3] - atu;       // (pi - a_i) - (theta - a_i)
+    return mx > 0.0 ? pmt : 0.5 * kPi;
+}
+
+// One matrix element through Dense,(Relu,Dense)* with the fast float64 helpers (same formulas as layer_map).
+__device__ __forceinline__ void layer_map_fast(double k, double q1, double q2, const ArchDev& arch, bool exact_diag,
+                                               const double* __restrict__ tab, double& out_k, double& out_t) {
+    double t = 0.0;
+    if (exact_diag) k = q1;
+    for (int l = 0; l < arch.n_dense; ++l) {
+        const double w2 = arch.w2[l], b2 = arch.b2[l];
+        k = fma(w2, k, b2);
+        q1 = fma(w2, q1, b2);
+        q2 = fma(w2, q2, b2);
+        t = fma(w2, t, k);
+        if (l < arch.n_dense - 1) {
+            if (exact_diag) {
+                k *= 0.5;
+                t *= 0.5;
+            } else {
+                const double r = fma(q1, q2, -k * k);
+                const double s = r > 0.0 ? fast_sqrt_pos(r > 0.0 ? r : 1.0) : 0.0;
+                const double kd = pi_minus_atan2(s, k, tab) * (0.5 / kPi);
+                k = fma(kd, k, s * (0.5 / kPi));
+                t *= kd;
+            }
+            q1 *= 0.5;
+            q2 *= 0.5;
+        }
+    }
+    out_k = k;
+    out_t = t;
+}
+
+template <typename T>
+__device__ __forceinline__ void store1(T* base, int64_t ld, int64_t i, int64_t j, double v) {
+    if (base != nullptr) base[i * ld + j] = (T)v;
+}
+
+// K1, second form.  One 64 x 64 output tile per 256-thread workgroup (4 waves, 32 x 32 each):
+//   * Gram entries on the float64 matrix cores (v_mfma_f64_16x16x4_f64, 2 x 2 blocks per wave).  The x1 / x2 row panels are
+//     staged through LDS in k-chunks of 32, ROW-major with a 2-double pad (stores run along k without bank conflicts, and a
+//     lane reads the two k values it feeds to two consecutive MFMAs with one 16-byte read);
+//   * the layer recursion runs in the MFMA accumulator layout -- no re-tiling pass -- with the fast float64 sqrt / atan2 above;
+//     rows of 16 consecutive doubles (128 bytes) leave each quarter-wave per store;
+//   * the mirror image of an off-diagonal tile goes through a per-WAVE transpose buffer in LDS (no workgroup barrier after
+//     the k-loop), 256 contiguous bytes per row and store instruction;
+//   * several workgroups are resident per CU (36 KB of LDS, < 128 VGPRs), so one workgroup's MFMA phase overlaps another's
+//     VALU epilogue and stores: the matrix and vector pipes are separate;
+//   * tiles are dealt to the XCDs in 8 x 8 super-tiles (512 x 512 entries): workgroup b runs on XCD b % 8, and the 64 tiles of a
+//     super-tile share 16 row panels of X through that XCD's L2 instead of fetching 128 KB per tile from the Infinity Cache.
+constexpr int MKC = 32;       // k-chunk
+constexpr int MLD = MKC + 2;  // LDS row stride (doubles): rows 16-byte aligned, quarter-waves on distinct banks
+constexpr int TLD = 34;       // row stride of the per-wave 32 x 32 transpose buffer
+
+__global__ __launch_bounds__(256, 2) void k_build_mfma(BuildArgs a, ArchDev arch, int64_t tiles_r, int64_t tiles_c,
+                                                       int64_t sup_r, int64_t sup_c, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * KT * MLD];  // As | Bs in the k-loop, 4 transpose buffers afterwards
+    __shared__ __attribute__((aligned(16))) double tab[65 * 4];
+    double* As = smem;             // [KT][MLD]
+    double* Bs = smem + KT * MLD;  // [KT][MLD]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 65 * 4; i += 256) tab[i] = kTrigTab[i >> 2][i & 3];
+
+    // workgroup -> tile: XCD = blockIdx % 8; each XCD walks whole super-tiles of 8 x 8 tiles
+    const int64_t b = blockIdx.x;
+    const int64_t local = b >> 3, sid = (local >> 6) * 8 + (b & 7);
+    const int slot = (int)(local & 63);
+    int64_t sbi, sbj;
+    if (a.sym) {
+        if (sid >= sup_r * (sup_r + 1) / 2) return;
+        sbi = (int64_t)((sqrt(8.0 * (double)sid + 1.0) - 1.0) * 0.5);
+        while (sbi * (sbi + 1) / 2 > sid) --sbi;
+        while ((sbi + 1) * (sbi + 2) / 2 <= sid) ++sbi;
+        sbj = sid - sbi * (sbi + 1) / 2;
+    } else {
+        if (sid >= sup_r * sup_c) return;
+        sbi = sid / sup_c;
+        sbj = sid % sup_c;
+    }
+    const int64_t bi = sbi * 8 + (slot >> 3), bj = sbj * 8 + (slot & 7);
+    if (bi >= tiles_r || bj >= tiles_c || (a.sym && bj > bi)) return;
+    const int64_t i0 = a.row_begin + bi * KT, j0 = bj * KT;
+    const int64_t i_end = a.row_end, j_end = a.n2;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, lg = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+    // global -> registers -> LDS, one chunk ahead of the MFMAs
+    double ra[8], rb[8];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;
+            const int kk = idx & (MKC - 1), row = idx >> 5;
+            const int kg = k0 + kk;
+            const int64_t gi = i0 + row, gj = j0 + row;
+            ra[e] = (kg < a.d && gi < i_end) ? a.x1[gi * a.d + kg] : 0.0;
+            rb[e] = (kg < a.d && gj < j_end) ? a.x2[gj * a.d + kg] : 0.0;
+        }
+    };
+    load_chunk(0);
+    for (int k0 = 0; k0 < a.d; k0 += MKC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;
+            const int kk = idx & (MKC - 1), row = idx >> 5;
+            As[row * MLD + kk] = ra[e];
+            Bs[row * MLD + kk] = rb[e];
+        }
+        __syncthreads();
+        if (k0 + MKC < a.d) load_chunk(k0 + MKC);
+#pragma unroll
+        for (int ks = 0; ks < MKC / 8; ++ks) {
+            double2 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const double2*>(&As[(wm * 32 + i * 16 + l16) * MLD + ks * 8 + 2 * lg]);
+                fb[i] = *reinterpret_cast<const double2*>(&Bs[(wn * 32 + i * 16 + l16) * MLD + ks * 8 + 2 * lg]);
+            }
+            // lane group g supplies k = 8 ks + 2 g (first MFMA) and 8 ks + 2 g + 1 (second): the sum over k does not care
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue in the accumulator layout: element (row = 16 i + lg + 4 r, col = 16 j + l16) of the wave's 32 x 32 block ----
+    const double inv_d = 1.0 / (double)a.d;
+    const int64_t wi0 = i0 + wm * 32, wj0 = j0 + wn * 32;
+    double q1v[2][4], q2v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = wi0 + i * 16 + lg + 4 * r;
+            q1v[i][r] = gi < i_end ? a.q1[gi] : 0.0;
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t gj = wj0 + j * 16 + l16;
+        q2v[j] = gj < j_end ? a.q2[gj] : 0.0;
+    }
+    const bool want_n = a.nngp64 != nullptr || a.nngp32 != nullptr, want_t = a.ntk64 != nullptr || a.ntk32 != nullptr;
+    const bool mirror = a.sym && bi != bj;
+    double* tbuf = smem + wave * (32 * TLD);  // this wave's transpose buffer (As / Bs are dead: the k-loop ended with a barrier)
+    double kt_keep[2][2][4];                  // NTK values wait for the second mirror pass
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = wi0 + i * 16 + lg + 4 * r, gj = wj0 + j * 16 + l16;
+                double kn, kt;
+                layer_map_fast(acc[i][j][r] * inv_d, q1v[i][r], q2v[j], arch, a.sym && gi == gj, tab, kn, kt);
+                kt_keep[i][j][r] = kt;
+                if (gi < i_end && gj < j_end) {
+                    store1(a.nngp64, a.ld64, gi, gj, kn);
+                    store1(a.ntk64, a.ld64, gi, gj, kt);
+                    const bool diag = a.sym && gi == gj;
+                    store1(a.nngp32, a.ld32, gi, gj, kn + (diag ? a.diag_add_nngp32 : 0.0));
+                    store1(a.ntk32, a.ld32, gi, gj, kt + (diag ? a.diag_add_ntk32 : 0.0));
+                }
+                if (mirror && want_n) tbuf[(j * 16 + l16) * TLD + i * 16 + lg + 4 * r] = kn;
+            }
+    if (!mirror) return;
+    // ---- mirror image: the wave's block transposed, rows of 32 doubles = 256 contiguous bytes ----
+    const bool vec = vec_ok != 0;
+    for (int which = 0; which < 2; ++which) {
+        if (which == 0 && !want_n) continue;
+        if (which == 1) {
+            if (!want_t) break;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tbuf[(j * 16 + l16) * TLD + i * 16 + lg + 4 * r] = kt_keep[i][j][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double* o64 = which == 0 ? a.nngp64 : a.ntk64;
+        float* o32 = a.lower32 ? nullptr : (which == 0 ? a.nngp32 : a.ntk32);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int trow = it * 4 + lg, tc = l16 * 2;
+            const double2 v = *reinterpret_cast<const double2*>(&tbuf[trow * TLD + tc]);
+            const int64_t mi = wj0 + trow, mj = wi0 + tc;  // element (mi, mj), (mi, mj + 1) of the mirror image
+            if (mi >= j_end) continue;
+            if (o64 != nullptr) {
+                if (vec && mj + 1 < i_end) *reinterpret_cast<double2*>(o64 + mi * a.ld64 + mj) = v;
+                else {
+                    if (mj < i_end) o64[mi * a.ld64 + mj] = v.x;
+                    if (mj + 1 < i_end) o64[mi * a.ld64 + mj + 1] = v.y;
+                }
+            }
+            if (o32 != nullptr) {
+                if (mj < i_end) o32[mi * a.ld32 + mj] = (float)v.x;
+                if (mj + 1 < i_end) o32[mi * a.ld32 + mj + 1] = (float)v.y;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_row_sqnorm(const double* x, int64_t n, int d, double* q, hipStream_t s) {
@@ -334,14 +602,23 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
     };
     int vec_ok = aligned(a.nngp64, a.ld64, 8) && aligned(a.ntk64, a.ld64, 8) && aligned(a.nngp32, a.ld32, 4) &&
                  aligned(a.ntk32, a.ld32, 4) && (a.row_begin % 4 == 0);
-    // Measured (scripts/k1_study.py, N=32768): per k-step the VALU Gram costs 0.026 ms (41 TFLOP/s float64), the MFMA
-    // Gram 0.038 ms -- on gfx950 the float64 MFMA rate EQUALS the float64 VALU rate (78.6 TF), so the matrix cores buy
-    // nothing here and add an LDS re-tiling pass; the VALU form is the default.  Where the 11 ms go at d=128, n_relu=3:
-    // 3.0 ms stores + tile overhead, 3.3 ms Gram, 1.7 ms per ReLU layer (sqrt + atan2 in float64).
-    if (NNGP_KNOB(3) == 3)
-        hipLaunchKernelGGL(k_build<true>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
-    else
-        hipLaunchKernelGGL(k_build<false>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
+    // Round 1 (scripts/k1_study.py, N=32768, d=128, n_relu=3): the all-VALU kernel k_build<false> took 10.7 ms -- 3.3 ms Gram
+    // (41 TF/s float64 FMA), 1.7 ms per ReLU layer (libm sqrt + atan2), 3.0 ms stores; its MFMA variant was slower because it
+    // re-tiled the accumulators through LDS and staged the panels k-major (8-way bank conflicts on the stores).  k_build_mfma
+    // keeps the epilogue in the accumulator layout, overlaps MFMA and VALU across co-resident workgroups and evaluates the
+    // map with the fast float64 helpers.  Debug key 3 = 4: the round-1 kernel, for A/B timing.
+    if (NNGP_KNOB(3) == 4 || NNGP_KNOB(3) == 3) {
+        if (NNGP_KNOB(3) == 3)
+            hipLaunchKernelGGL(k_build<true>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
+        else
+            hipLaunchKernelGGL(k_build<false>, dim3((unsigned)nblocks), dim3(256), 0, s, a, arch, tiles_c, vec_ok);
+    } else {
+        const int64_t sup_r = (tiles_r + 7) / 8, sup_c = (tiles_c + 7) / 8;
+        const int64_t nsup = a.sym ? sup_r * (sup_r + 1) / 2 : sup_r * sup_c;
+        const int64_t grid = ((nsup + 7) / 8) * 8 * 64;  // 64 tile slots per super-tile, super-tiles dealt round-robin to 8 XCDs
+        NNGP_REQUIRE(grid < (int64_t)2147483647, "kernel_build: grid too large (%lld workgroups)", (long long)grid);
+        hipLaunchKernelGGL(k_build_mfma, dim3((unsigned)grid), dim3(256), 0, s, a, arch, tiles_r, tiles_c, sup_r, sup_c, vec_ok);
+    }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -10,12 +10,12 @@ from nngp_src_amd.model import GPModel
 
 n = 32768
 out = {}
-for variant in (0, 3):
-    _lib.load().nngp_debug_set(3, variant)
+for variant in (0, 4):  # 0: k_build_mfma (default); 4: the round-1 all-VALU kernel
+    _lib.load(knobs=True).nngp_debug_set(3, variant)
     for d in (16, 128, 256):
         x, y = synth.synthetic_queries(n, d, seed=0)
         for n_relu in (0, 1, 3):
-            m = GPModel(n, d, [1.0] * (n_relu + 1), [0.0] * (n_relu + 1), diag_reg=1e-3)
+            m = GPModel(n, d, [1.0] * (n_relu + 1), [0.0] * (n_relu + 1), diag_reg=1e-3, knobs=True)
             m.set_train(x, y)
             m.build_rows(0, n); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,7 +23,7 @@ for variant in (0, 3):
             for _ in range(3):
                 m.build_rows(0, n)
             e1.record(); torch.cuda.synchronize()
-            out["%s_d%d_relu%d_ms" % ("mfma" if variant == 3 else "valu", d, n_relu)] = round(e0.elapsed_time(e1) / 3, 3)
+            out["%s_d%d_relu%d_ms" % ("valu_r1" if variant == 4 else "mfma", d, n_relu)] = round(e0.elapsed_time(e1) / 3, 3)
             m.close(); del m
-_lib.load().nngp_debug_set(3, 0)
+_lib.load(knobs=True).nngp_debug_set(3, 0)
 print(json.dumps(out, indent=1))

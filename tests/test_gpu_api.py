@@ -288,3 +288,28 @@ def test_c_abi_error_codes_instead_of_crashes():
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and (var > 0).all()
     lib.nngp_model_destroy(h)
+
+
+def test_checkpoint_save_and_resume(tmp_path):
+    """the reference keeps (X, factor, alpha) in a closure only.  GPModel.save writes what defines the fit
+    (X, Y, architecture, regulariser; alpha as the check value), GPModel.load refits on the device -- faster than reading a
+    factor back -- and must reproduce alpha, the means and the variances; appended rows are part of the state."""
+    n0, b, d = 900, 300, 24
+    x, y = synth.synthetic_queries(n0 + b, d, seed=12)
+    xt, _ = synth.synthetic_queries(77, d, seed=13)
+    model = GPModel(n0 + b, d, [1.2, 1.0, 0.9], [0.1, 0.0, 0.2], get="nngp", diag_reg=2e-3).fit(x[:n0], y[:n0])
+    model.append(x[n0:], y[n0:])
+    mean, var = model.predict(xt, cov="diag")
+    path = str(tmp_path / "fit.npz")
+    model.save(path)
+    again = GPModel.load(path)
+    assert again.n == n0 + b and again.get == "nngp"
+    mean2, var2 = again.predict(xt, cov="diag")
+    np.testing.assert_allclose(mean2, mean, rtol=1e-8, atol=1e-9 * np.abs(mean).max())
+    np.testing.assert_allclose(var2, var, rtol=1e-5)
+    # a checkpoint that does not reproduce is refused
+    z = dict(np.load(path))
+    z["alpha"] = z["alpha"] * 1.001
+    np.savez(str(tmp_path / "bad.npz"), **z)
+    with pytest.raises(Exception):
+        GPModel.load(str(tmp_path / "bad.npz"))

