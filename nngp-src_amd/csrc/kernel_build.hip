@@ -299,29 +299,22 @@ __global__ __launch_bounds__(256) void k_build(BuildArgs a, ArchDev arch, int64_
     }
 }
 
-// ---- float64 arithmetic of the ReLU map at ~1/3 of the libm cost (the epilogue is VALU-bound) --------------------------
-// 1 / x: v_rcp_f64 seed (>= 2^-26) + two Newton steps.  x > 0.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+// ---- float64 arithmetic of the ReLU map at ~1/2 of the libm cost (the epilogue is bound by the float64 ALUs) ---------------
+// Measured on gfx950 (scripts/micro/f64_seed_accuracy.hip, 2^24 inputs over 2^-20 .. 2^21): v_rcp_f64 is good to 2^-24.4 and one
+// Newton step brings it to 2.2e-15; v_rsq_f64 is good to 2^-24.2 and one coupled (Goldschmidt) iteration plus the residual
+// correction reproduces the correctly rounded sqrt on every input tried.
+__device__ __forceinline__ double fast_rcp(double x) {  // 1 / x to 2.2e-15, x > 0
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
 }
 
-// sqrt(r), r > 0: v_rsq_f64 seed, two coupled (Goldschmidt) iterations for g ~ sqrt(r), h ~ 1 / (2 sqrt(r)), and the residual
-// correction that makes the result faithful to the last bit or two.
-__device__ __forceinline__ double fast_sqrt_pos(double r) {
+__device__ __forceinline__ double fast_sqrt_pos(double r) {  // sqrt(r), r > 0
     const double y = __builtin_amdgcn_rsq(r);
     double g = r * y, h = 0.5 * y;
-    double e = fma(-h, g, 0.5);
+    const double e = fma(-h, g, 0.5);
     g = fma(g, e, g);
     h = fma(h, e, h);
-    e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    const double d = fma(-g, g, r);
-    return fma(d, h, g);
+    return fma(fma(-g, g, r), h, g);
 }
 
 // pi - atan2(s, k) for s >= 0 (what the ReLU map needs; s = k = 0 gives pi / 2, the reference's fill value).
@@ -351,65 +344,39 @@ __device__ __forceinline__ double pi_minus_atan2(double s, double k, const doubl
     return mx > 0.0 ? pmt : 0.5 * kPi;
 }
 
-// One matrix element through Dense,(Relu,Dense)* with the fast float64 helpers (same formulas as layer_map).
-__device__ __forceinline__ void layer_map_fast(double k, double q1, double q2, const ArchDev& arch, bool exact_diag,
-                                               const double* __restrict__ tab, double& out_k, double& out_t) {
-    double t = 0.0;
-    if (exact_diag) k = q1;
-    for (int l = 0; l < arch.n_dense; ++l) {
-        const double w2 = arch.w2[l], b2 = arch.b2[l];
-        k = fma(w2, k, b2);
-        q1 = fma(w2, q1, b2);
-        q2 = fma(w2, q2, b2);
-        t = fma(w2, t, k);
-        if (l < arch.n_dense - 1) {
-            if (exact_diag) {
-                k *= 0.5;
-                t *= 0.5;
-            } else {
-                const double r = fma(q1, q2, -k * k);
-                const double s = r > 0.0 ? fast_sqrt_pos(r > 0.0 ? r : 1.0) : 0.0;
-                const double kd = pi_minus_atan2(s, k, tab) * (0.5 / kPi);
-                k = fma(kd, k, s * (0.5 / kPi));
-                t *= kd;
-            }
-            q1 *= 0.5;
-            q2 *= 0.5;
-        }
-    }
-    out_k = k;
-    out_t = t;
-}
-
-template <typename T>
-__device__ __forceinline__ void store1(T* base, int64_t ld, int64_t i, int64_t j, double v) {
-    if (base != nullptr) base[i * ld + j] = (T)v;
-}
-
-// K1, second form.  One 64 x 64 output tile per 256-thread workgroup (4 waves, 32 x 32 each):
+// K1, second form.  One 64 x 64 output tile per 256-thread workgroup (4 waves, 32 x 32 outputs each), MANY workgroups per CU:
 //   * Gram entries on the float64 matrix cores (v_mfma_f64_16x16x4_f64, 2 x 2 blocks per wave).  The x1 / x2 row panels are
-//     staged through LDS in k-chunks of 32, ROW-major with a 2-double pad (stores run along k without bank conflicts, and a
+//     staged through LDS in k-chunks of 16, ROW-major with a 2-double pad (stores run along k without bank conflicts, and a
 //     lane reads the two k values it feeds to two consecutive MFMAs with one 16-byte read);
-//   * the layer recursion runs in the MFMA accumulator layout -- no re-tiling pass -- with the fast float64 sqrt / atan2 above;
-//     rows of 16 consecutive doubles (128 bytes) leave each quarter-wave per store;
-//   * the mirror image of an off-diagonal tile goes through a per-WAVE transpose buffer in LDS (no workgroup barrier after
-//     the k-loop), 256 contiguous bytes per row and store instruction;
-//   * several workgroups are resident per CU (36 KB of LDS, < 128 VGPRs), so one workgroup's MFMA phase overlaps another's
-//     VALU epilogue and stores: the matrix and vector pipes are separate;
+//   * the layer recursion runs in the MFMA accumulator layout -- no re-tiling pass -- one 16 x 16 block (4 entries per lane)
+//     at a time, with the fast float64 sqrt / atan2 above;
+//   * results leave through a per-WAVE 16 x 32 buffer in LDS: read back by rows for the tile itself and by columns for its
+//     mirror image (symmetric build), so every global store is 16 bytes per lane in runs of 128 / 256 contiguous bytes -- and
+//     no workgroup barrier is needed after the k-loop;
+//   * <= 128 VGPRs and 21 KB of LDS: 4 workgroups per CU.  The phases of a tile are serial (panel loads -> MFMAs -> layer map
+//     -> stores), so the float64 ALUs are only kept busy by OTHER workgroups' phases.  (Measured: a persistent-workgroup form
+//     with 2 workgroups per CU was slower than one tile per workgroup, 8.1 vs 7.4 ms at N = 32768.)
 //   * tiles are dealt to the XCDs in 8 x 8 super-tiles (512 x 512 entries): workgroup b runs on XCD b % 8, and the 64 tiles of a
 //     super-tile share 16 row panels of X through that XCD's L2 instead of fetching 128 KB per tile from the Infinity Cache.
-constexpr int MKC = 32;       // k-chunk
-constexpr int MLD = MKC + 2;  // LDS row stride (doubles): rows 16-byte aligned, quarter-waves on distinct banks
-constexpr int TLD = 34;       // row stride of the per-wave 32 x 32 transpose buffer
+// Bound: the float64 ALUs.  On gfx950 v_mfma_f64 and the float64 VALU instructions do NOT overlap -- a kernel whose even waves
+// issue only float64 MFMAs and whose odd waves issue only float64 FMAs takes the SUM of the two times, not the maximum
+// (scripts/micro/f64_pipes.hip: 17.2 ms MFMA, 21.1 ms FMA, 18.7 ms half / half) -- so Gram and layer map add up.
+constexpr int TLD = 34;       // row stride of the per-wave 16 x 32 output buffer
 
-__global__ __launch_bounds__(256, 2) void k_build_mfma(BuildArgs a, ArchDev arch, int64_t tiles_r, int64_t tiles_c,
-                                                       int64_t sup_r, int64_t sup_c, int vec_ok) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * KT * MLD];  // As | Bs in the k-loop, 4 transpose buffers afterwards
+// MKC: k-chunk; PREFETCH: the next chunk's global loads are issued into registers before the MFMAs of the current one;
+// MINWG: workgroups per CU the register allocation must allow; LDSOUT: tile + mirror leave through the LDS buffer with 16-byte
+// stores (false: the tile itself is stored straight from the accumulator layout, 8 bytes per lane).
+template <int MKC, bool PREFETCH, int MINWG, bool LDSOUT>
+__global__ __launch_bounds__(256, MINWG) void k_build_mfma(BuildArgs a, ArchDev arch, int64_t tiles_r, int64_t tiles_c,
+                                                           int64_t sup_r, int64_t sup_c, int vec_ok, int ablate) {
+    constexpr int MLD = MKC + 2;  // LDS row stride (doubles): rows 16-byte aligned, quarter-waves on distinct banks
+    constexpr int NLD = MKC * 64 / 256;  // doubles per thread and operand per chunk
+    __shared__ __attribute__((aligned(16))) double smem[2 * KT * MLD];  // As | Bs in the k-loop, 4 output buffers afterwards
     __shared__ __attribute__((aligned(16))) double tab[65 * 4];
+    static_assert(4 * 16 * TLD <= 2 * KT * MLD, "the output buffers alias the panel buffers");
     double* As = smem;             // [KT][MLD]
     double* Bs = smem + KT * MLD;  // [KT][MLD]
     const int tid = threadIdx.x;
-    for (int i = tid; i < 65 * 4; i += 256) tab[i] = kTrigTab[i >> 2][i & 3];
 
     // workgroup -> tile: XCD = blockIdx % 8; each XCD walks whole super-tiles of 8 x 8 tiles
     const int64_t b = blockIdx.x;
@@ -431,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void k_build_mfma(BuildArgs a, ArchDev arch
     if (bi >= tiles_r || bj >= tiles_c || (a.sym && bj > bi)) return;
     const int64_t i0 = a.row_begin + bi * KT, j0 = bj * KT;
     const int64_t i_end = a.row_end, j_end = a.n2;
+    for (int i = tid; i < 65 * 4; i += 256) tab[i] = kTrigTab[i >> 2][i & 3];
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, lg = lane >> 4;
@@ -442,30 +410,30 @@ __global__ __launch_bounds__(256, 2) void k_build_mfma(BuildArgs a, ArchDev arch
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
-    // global -> registers -> LDS, one chunk ahead of the MFMAs
-    double ra[8], rb[8];
-    auto load_chunk = [&](int k0) {
+    double ra[NLD], rb[NLD];
+    auto load_chunk = [&](int k0) {  // 64 rows x MKC k per operand, lanes along k
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < NLD; ++e) {
             const int idx = tid + 256 * e;
-            const int kk = idx & (MKC - 1), row = idx >> 5;
+            const int kk = idx & (MKC - 1), row = idx / MKC;
             const int kg = k0 + kk;
             const int64_t gi = i0 + row, gj = j0 + row;
             ra[e] = (kg < a.d && gi < i_end) ? a.x1[gi * a.d + kg] : 0.0;
             rb[e] = (kg < a.d && gj < j_end) ? a.x2[gj * a.d + kg] : 0.0;
         }
     };
-    load_chunk(0);
-    for (int k0 = 0; k0 < a.d; k0 += MKC) {
+    if (PREFETCH) load_chunk(0);
+    for (int k0 = 0; k0 < ((ablate & 2) ? MKC : a.d); k0 += MKC) {
+        if (!PREFETCH) load_chunk(k0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < NLD; ++e) {
             const int idx = tid + 256 * e;
-            const int kk = idx & (MKC - 1), row = idx >> 5;
+            const int kk = idx & (MKC - 1), row = idx / MKC;
             As[row * MLD + kk] = ra[e];
             Bs[row * MLD + kk] = rb[e];
         }
         __syncthreads();
-        if (k0 + MKC < a.d) load_chunk(k0 + MKC);
+        if (PREFETCH && k0 + MKC < a.d) load_chunk(k0 + MKC);
 #pragma unroll
         for (int ks = 0; ks < MKC / 8; ++ks) {
             double2 fa[2], fb[2];
@@ -486,84 +454,155 @@ __global__ __launch_bounds__(256, 2) void k_build_mfma(BuildArgs a, ArchDev arch
         __syncthreads();
     }
 
-    // ---- epilogue in the accumulator layout: element (row = 16 i + lg + 4 r, col = 16 j + l16) of the wave's 32 x 32 block ----
+    // ---- layer recursion in the accumulator layout: entry (row = 16 i + lg + 4 r, col = 16 j + l16) of the wave's block ----
     const double inv_d = 1.0 / (double)a.d;
     const int64_t wi0 = i0 + wm * 32, wj0 = j0 + wn * 32;
-    double q1v[2][4], q2v[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t gi = wi0 + i * 16 + lg + 4 * r;
-            q1v[i][r] = gi < i_end ? a.q1[gi] : 0.0;
-        }
+    const bool diag_tile = a.sym && bi == bj && wm == wn;  // entries (i, i) exist only in these blocks
+    const bool mirror = a.sym && bi != bj;
+    const bool vec = vec_ok != 0;
+    const bool want_t = a.ntk64 != nullptr || a.ntk32 != nullptr;
+    double* tbuf = smem + wave * (16 * TLD);  // this wave's output buffer (As / Bs are dead: the k-loop ended with a barrier)
+    double q2in[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int64_t gj = wj0 + j * 16 + l16;
-        q2v[j] = gj < j_end ? a.q2[gj] : 0.0;
+        q2in[j] = gj < j_end ? a.q2[gj] : 0.0;
     }
-    const bool want_n = a.nngp64 != nullptr || a.nngp32 != nullptr, want_t = a.ntk64 != nullptr || a.ntk32 != nullptr;
-    const bool mirror = a.sym && bi != bj;
-    double* tbuf = smem + wave * (32 * TLD);  // this wave's transpose buffer (As / Bs are dead: the k-loop ended with a barrier)
-    double kt_keep[2][2][4];                  // NTK values wait for the second mirror pass
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {  // 16 rows x 32 columns of the wave's block per pass
+        double q1in[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = wi0 + i * 16 + lg + 4 * r;
+            q1in[r] = gi < i_end ? a.q1[gi] : 0.0;
+        }
+        double kv[2][4], tv[2][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const f64x4 av = i == 0 ? acc[0][j] : acc[1][j];
+            double q1v[4], q2v = q2in[j];
+            bool dg[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t gi = wi0 + i * 16 + lg + 4 * r, gj = wj0 + j * 16 + l16;
-                double kn, kt;
-                layer_map_fast(acc[i][j][r] * inv_d, q1v[i][r], q2v[j], arch, a.sym && gi == gj, tab, kn, kt);
-                kt_keep[i][j][r] = kt;
-                if (gi < i_end && gj < j_end) {
-                    store1(a.nngp64, a.ld64, gi, gj, kn);
-                    store1(a.ntk64, a.ld64, gi, gj, kt);
-                    const bool diag = a.sym && gi == gj;
-                    store1(a.nngp32, a.ld32, gi, gj, kn + (diag ? a.diag_add_nngp32 : 0.0));
-                    store1(a.ntk32, a.ld32, gi, gj, kt + (diag ? a.diag_add_ntk32 : 0.0));
-                }
-                if (mirror && want_n) tbuf[(j * 16 + l16) * TLD + i * 16 + lg + 4 * r] = kn;
+                q1v[r] = q1in[r];
+                dg[r] = diag_tile && i == j && lg + 4 * r == l16;
+                kv[j][r] = dg[r] ? q1v[r] : av[r] * inv_d;  // exact diagonal: q q' - k^2 == 0 must hold exactly
+                tv[j][r] = 0.0;
             }
-    if (!mirror) return;
-    // ---- mirror image: the wave's block transposed, rows of 32 doubles = 256 contiguous bytes ----
-    const bool vec = vec_ok != 0;
-    for (int which = 0; which < 2; ++which) {
-        if (which == 0 && !want_n) continue;
-        if (which == 1) {
-            if (!want_t) break;
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int l = 0; l < arch.n_dense; ++l) {
+                const double w2 = arch.w2[l], b2 = arch.b2[l];
+                const bool relu = l < arch.n_dense - 1 && !(ablate & 4);
+                q2v = fma(w2, q2v, b2);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tbuf[(j * 16 + l16) * TLD + i * 16 + lg + 4 * r] = kt_keep[i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    q1v[r] = fma(w2, q1v[r], b2);
+                    double k = fma(w2, kv[j][r], b2);
+                    double t = fma(w2, tv[j][r], k);
+                    if (relu) {
+                        const double rr = dg[r] ? 0.0 : fma(q1v[r], q2v, -k * k);
+                        const double s = rr > 0.0 ? fast_sqrt_pos(rr > 0.0 ? rr : 1.0) : 0.0;
+                        double kd = pi_minus_atan2(s, k, tab) * (0.5 / kPi);
+                        kd = dg[r] ? 0.5 : kd;  // theta = 0 on the diagonal, exactly
+                        k = fma(kd, k, s * (0.5 / kPi));
+                        t *= kd;
+                    }
+                    kv[j][r] = k;
+                    tv[j][r] = t;
+                    q1v[r] *= 0.5;
+                }
+                q2v *= 0.5;
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        double* o64 = which == 0 ? a.nngp64 : a.ntk64;
-        float* o32 = a.lower32 ? nullptr : (which == 0 ? a.nngp32 : a.ntk32);
+        if ((ablate & 1) && kv[0][0] != 12345.678 && tv[1][3] != 12345.678) continue;
+        if (!LDSOUT) {  // the tile itself straight from the accumulator layout: 16 lanes x 8 bytes = one 128-byte line per row piece
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int trow = it * 4 + lg, tc = l16 * 2;
-            const double2 v = *reinterpret_cast<const double2*>(&tbuf[trow * TLD + tc]);
-            const int64_t mi = wj0 + trow, mj = wi0 + tc;  // element (mi, mj), (mi, mj + 1) of the mirror image
-            if (mi >= j_end) continue;
-            if (o64 != nullptr) {
-                if (vec && mj + 1 < i_end) *reinterpret_cast<double2*>(o64 + mi * a.ld64 + mj) = v;
-                else {
-                    if (mj < i_end) o64[mi * a.ld64 + mj] = v.x;
-                    if (mj + 1 < i_end) o64[mi * a.ld64 + mj + 1] = v.y;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gi = wi0 + i * 16 + lg + 4 * r, gj = wj0 + j * 16 + l16;
+                    if (gi < i_end && gj < j_end) {
+                        const bool dgl = a.sym && gi == gj;
+                        if (a.nngp64) a.nngp64[gi * a.ld64 + gj] = kv[j][r];
+                        if (a.ntk64) a.ntk64[gi * a.ld64 + gj] = tv[j][r];
+                        if (a.nngp32) a.nngp32[gi * a.ld32 + gj] = (float)(kv[j][r] + (dgl ? a.diag_add_nngp32 : 0.0));
+                        if (a.ntk32) a.ntk32[gi * a.ld32 + gj] = (float)(tv[j][r] + (dgl ? a.diag_add_ntk32 : 0.0));
+                    }
+                }
+            if (!mirror) continue;
+        }
+
+        // ---- out through the wave's LDS buffer: rows for the tile, columns for its mirror image ----
+        for (int which = 0; which < 2; ++which) {
+            double* o64 = which == 0 ? a.nngp64 : a.ntk64;
+            float* o32 = which == 0 ? a.nngp32 : a.ntk32;
+            if (o64 == nullptr && o32 == nullptr) continue;
+            const double dadd = which == 0 ? a.diag_add_nngp32 : a.diag_add_ntk32;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous pass's reads of tbuf
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tbuf[(lg + 4 * r) * TLD + j * 16 + l16] = which == 0 ? kv[j][r] : tv[j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int64_t r0 = wi0 + i * 16;  // first global row of this pass
+            if (LDSOUT && o64 != nullptr) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {  // 4 rows x 32 columns per store instruction, 16 bytes per lane
+                    const int trow = it * 4 + lg, tc = l16 * 2;
+                    const double2 v = *reinterpret_cast<const double2*>(&tbuf[trow * TLD + tc]);
+                    const int64_t gi = r0 + trow, gj = wj0 + tc;
+                    if (gi >= i_end) continue;
+                    if (vec && gj + 1 < j_end) *reinterpret_cast<double2*>(o64 + gi * a.ld64 + gj) = v;
+                    else {
+                        if (gj < j_end) o64[gi * a.ld64 + gj] = v.x;
+                        if (gj + 1 < j_end) o64[gi * a.ld64 + gj + 1] = v.y;
+                    }
                 }
             }
-            if (o32 != nullptr) {
-                if (mj < i_end) o32[mi * a.ld32 + mj] = (float)v.x;
-                if (mj + 1 < i_end) o32[mi * a.ld32 + mj + 1] = (float)v.y;
+            if (LDSOUT && o32 != nullptr) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {  // 8 rows x 32 columns per store instruction, 4 floats per lane
+                    const int trow = it * 8 + (lane >> 3), tc = (lane & 7) * 4;
+                    const double2 v0 = *reinterpret_cast<const double2*>(&tbuf[trow * TLD + tc]);
+                    const double2 v1 = *reinterpret_cast<const double2*>(&tbuf[trow * TLD + tc + 2]);
+                    const int64_t gi = r0 + trow, gj = wj0 + tc;
+                    if (gi >= i_end) continue;
+                    double v[4] = {v0.x, v0.y, v1.x, v1.y};
+                    if (a.sym)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] += (gi == gj + c) ? dadd : 0.0;
+                    float* dst = o32 + gi * a.ld32 + gj;
+                    if (vec && gj + 3 < j_end) *reinterpret_cast<float4*>(dst) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                    else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (gj + c < j_end) dst[c] = (float)v[c];
+                }
+            }
+            if (!mirror) continue;
+            float* m32 = a.lower32 ? nullptr : o32;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {  // mirror image: 32 rows (the block's columns) of 16 entries, 8 rows per instruction
+                const int mrow = it * 8 + (lane >> 3), mc = (lane & 7) * 2;
+                const double vx = tbuf[mc * TLD + mrow], vy = tbuf[(mc + 1) * TLD + mrow];
+                const int64_t mi = wj0 + mrow, mj = r0 + mc;
+                if (mi >= j_end) continue;
+                if (o64 != nullptr) {
+                    if (vec && mj + 1 < i_end) *reinterpret_cast<double2*>(o64 + mi * a.ld64 + mj) = make_double2(vx, vy);
+                    else {
+                        if (mj < i_end) o64[mi * a.ld64 + mj] = vx;
+                        if (mj + 1 < i_end) o64[mi * a.ld64 + mj + 1] = vy;
+                    }
+                }
+                if (m32 != nullptr) {
+                    if (mj < i_end) m32[mi * a.ld32 + mj] = (float)vx;
+                    if (mj + 1 < i_end) m32[mi * a.ld32 + mj + 1] = (float)vy;
+                }
             }
         }
     }
+    (void)want_t;
 }
 
 }  // namespace
@@ -580,6 +619,18 @@ int launch_diag_from_q(const double* q, int64_t n, const ArchDev& arch, double* 
     hipLaunchKernelGGL(k_diag_from_q, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, n, arch, dn, dt);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+static int device_cus() {
+    static std::atomic<int> cached{0};
+    int n = cached.load(std::memory_order_relaxed);
+    if (n == 0) {
+        int dev = 0, count = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+             count >= 8) ? count : 256;
+        cached.store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) {
@@ -617,7 +668,22 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
         const int64_t nsup = a.sym ? sup_r * (sup_r + 1) / 2 : sup_r * sup_c;
         const int64_t grid = ((nsup + 7) / 8) * 8 * 64;  // 64 tile slots per super-tile, super-tiles dealt round-robin to 8 XCDs
         NNGP_REQUIRE(grid < (int64_t)2147483647, "kernel_build: grid too large (%lld workgroups)", (long long)grid);
-        hipLaunchKernelGGL(k_build_mfma, dim3((unsigned)grid), dim3(256), 0, s, a, arch, tiles_r, tiles_c, sup_r, sup_c, vec_ok);
+        const int ablate = NNGP_KNOB(3) >= 32 && NNGP_KNOB(3) < 40 ? NNGP_KNOB(3) - 32 : 0;  // timing ablations (wrong results)
+        const int variant = NNGP_KNOB(5) >= 20 && NNGP_KNOB(5) < 30 ? NNGP_KNOB(5) - 20 : 0;  // A/B timing of the kernel forms
+#define NNGP_K1_LAUNCH(KC_, PF_, WG_, LO_) \
+        hipLaunchKernelGGL((k_build_mfma<KC_, PF_, WG_, LO_>), dim3((unsigned)grid), dim3(256), 0, s, a, arch, tiles_r, tiles_c, sup_r, sup_c, vec_ok, ablate)
+        switch (variant) {
+#ifdef NNGP_TIMING_KNOBS  // measured (scripts/k1_variants.py, ms at N = 32768, d = 128, n_relu = 3; all stores / no stores):
+            case 1: NNGP_K1_LAUNCH(16, false, 4, true); break;   // 7.66 / 5.82  (29 registers spilled)
+            case 2: NNGP_K1_LAUNCH(32, true, 3, false); break;   // 6.76 / 6.17
+            case 3: NNGP_K1_LAUNCH(32, true, 3, true); break;    // 6.74 / 6.11
+            case 4: NNGP_K1_LAUNCH(32, true, 4, false); break;   // 7.11 / 5.90  (25 spilled)
+            case 5: NNGP_K1_LAUNCH(16, true, 4, false); break;   // 7.00 / 5.81  (24 spilled)
+            case 7: NNGP_K1_LAUNCH(32, false, 4, false); break;  // 7.23 / 5.81  (24 spilled)
+#endif
+            default: NNGP_K1_LAUNCH(16, true, 3, false); break;  // 6.7 ms at N = 32768, d = 128, n_relu = 3 (round 1: 10.1)
+        }
+#undef NNGP_K1_LAUNCH
     }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
