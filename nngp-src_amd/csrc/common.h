@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...);
 //   3  (also) 40 + e = stopping tolerance 10^-e of the early-stopped alpha CG (scripts/partial_tol_study.py)
 //   1  block-column width of the look-ahead Cholesky (default 1024)
 //   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA; 3 = panel-solve product on the
-//      float32 MFMA (trailing updates stay on the float16 pipe)
+//      float32 MFMA (trailing updates stay on the float16 pipe); 4 = round-1 panel solves (GEMM recursion instead of trsm_panel.hip)
 //   3  1 = slower leaf variant; 3 = kernel build with the float64-MFMA Gram product; 10 + n = first n block columns of the
 //      Cholesky on the float32 MFMA; 20 + c = float32 lead of 128 c columns in the first trailing update (default 256)
 //   4  compute units the persistent split-float16 grid leaves free (default 32 in the Cholesky); panel CUs of the CU-mask
@@ -122,6 +122,10 @@ int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped,
 int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s);
 int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
                  hipStream_t s);
+
+// ---- trsm_panel.hip: b [m, w] <- b L^-T in one launch (w <= 1024), optionally with the rows' float16 split copy ----
+int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t w,
+                          char* planes, int64_t ldp, float scale, hipStream_t s);
 
 struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one per model
     char* planes = nullptr;    // [ncols][rows_cap][k_cap] x 4 bytes: L by block column k, row index = global row

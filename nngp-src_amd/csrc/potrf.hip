@@ -249,6 +249,10 @@ int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, 
         // in place: C aliases A, one column tile (see gemm_f32.hip header)
         return launch_gemm_nt_f32(b, ldb, b, ldb, dinv, TB, m, TB, TB, 1.0f, 0.0f, false, s);
     }
+    // up to 1024 columns: one fused launch, 32 rows per workgroup resident in LDS (trsm_panel.hip) instead of a recursion of
+    // 2 n / 128 - 1 small GEMMs (debug key 2 = 4: the recursion, for A/B timing)
+    if (n <= 1024 && m % 32 == 0 && NNGP_KNOB(2) != 4)
+        return launch_trsm_panel_f32(b, ldb, m, l, ldl, dinv, n, nullptr, 0, 1.0f, s);
     const int64_t n1 = (n / TB / 2) * TB, n2 = n - n1;
     NNGP_TRY(trsm_rlt_f32(b, ldb, m, l, ldl, dinv, n1, s));
     // B2 -= B1 * L21^T,  L21 = L[n1:, :n1]
@@ -392,38 +396,53 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         const float* p = akk + nbk * ld;        // panel rows below the diagonal block: [m, nbk]
         float* c = akk + nbk * ld + nbk;        // trailing matrix: [m, m]
         // critical path first: solve only the nb2 panel rows the next diagonal block needs, update that block, and
-        // release the panel stream; the remaining panel rows and the rest of the trailing update follow
-        rc = trsm_rlt_f32(akk + nbk * ld, ld, nb2, akk, ld, dk, nbk, la->update);
+        // release the panel stream; the remaining panel rows and the rest of the trailing update follow.  Both solves are
+        // single fused launches (trsm_panel.hip) that also leave the rows' float16 split copy in this block column's planes
+        // (rows at their global index: the trailing update and, later, the posterior's blocked solves read them there).
+        const bool fused = NNGP_KNOB(2) != 4 && nbk <= 1024;
+        const bool planes_here = h3 && nbk == nb && fused;
+        const int64_t ldp = h3 ? 4 * sw->k_cap : 0;
+        char* pk_rows = h3 ? sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp : nullptr;  // split copy of row o + nbk
+        if (fused)
+            rc = launch_trsm_panel_f32(akk + nbk * ld, ld, nb2, akk, ld, dk, nbk, planes_here ? pk_rows : nullptr, ldp,
+                                       h3 ? sw->scale : 1.0f, la->update);
+        else
+            rc = trsm_rlt_f32(akk + nbk * ld, ld, nb2, akk, ld, dk, nbk, la->update);
         if (rc == 0) rc = launch_gemm_nt_f32(c, ld, p, ld, p, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, la->update);
         NNGP_HIP_CHECK(hipEventRecord(la->ev_col[k], la->update));
         // ... then the other panel rows and the rest of the trailing matrix, overlapped with the next diagonal block
         if (rc == 0 && m > nb2) {
-            // The solve of the remaining panel rows, X = B L_kk^-T, splits as X1 = B1 L11^-T, B2 -= X1 L21^T, X2 = B2 L22^-T
-            // over the two 512-column halves; the product in the middle is half of its work.  From the second block column
-            // on it runs on the float16 pipe too: X1 is split straight into its place in this block column's planes (the
-            // trailing update needs it there anyway), L21 into the planes' unused rows of the diagonal block.  (Block
-            // column 0 stays on the float32 MFMA: same-sign data, see below.  Debug key 2 = 3: float32 product.)
-            const bool h3_panel = h3 && k > 0 && nbk == nb && nb == 1024 && m - nb2 >= 2048 && NNGP_KNOB(2) != 3 &&
-                                  !(NNGP_KNOB(3) >= 10 && NNGP_KNOB(3) < 20 && k < NNGP_KNOB(3) - 10);
             panel_split_done = false;
-            if (h3_panel) {
-                const int64_t ldp = 4 * sw->k_cap, h = nbk / 2, mr = m - nb2;
-                char* pk = sw->planes + (int64_t)k * sw->col_stride;        // planes of block column k, global row 0
-                char* xrows = pk + (o + nbk + nb2) * ldp;                    // rows of the panel being solved
-                float* b = akk + (nbk + nb2) * ld;
-                rc = trsm_rlt_f32(b, ld, mr, akk, ld, dk, h, la->update);                                  // X1
-                if (rc == 0) rc = launch_split_rows(b, ld, mr, h, sw->scale, xrows, ldp, la->update);
-                if (rc == 0) rc = launch_split_rows(akk + h * ld, ld, h, h, sw->scale, pk + (o + h) * ldp, ldp, la->update);  // L21
-                if (rc == 0)
-                    rc = launch_gemm_nt_h3(b + h, ld, xrows, pk + (o + h) * ldp, ldp, mr, h, h, -1.0f / (sw->scale * sw->scale), 1.0f,
-                                           false, 0, sw->counters, NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32, la->update);
-                if (rc == 0) rc = trsm_rlt_f32(b + h, ld, mr, akk + h * ld + h, ld, dk + (h / TB) * TB * TB, h, la->update);  // X2
-                if (rc == 0) rc = launch_split_rows(b + h, ld, mr, h, sw->scale, xrows + h * 4, ldp, la->update);
-                if (rc == 0)  // the rows solved first (critical path) go into the planes as well
-                    rc = launch_split_rows(p, ld, nb2, nbk, sw->scale, pk + (o + nbk) * ldp, ldp, la->update);
-                panel_split_done = true;
+            if (fused) {
+                rc = launch_trsm_panel_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk,
+                                           planes_here ? pk_rows + nb2 * ldp : nullptr, ldp, h3 ? sw->scale : 1.0f, la->update);
+                panel_split_done = planes_here;
             } else {
-                rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
+                // Round-1 form (debug key 2 = 4).  The solve of the remaining panel rows, X = B L_kk^-T, splits as
+                // X1 = B1 L11^-T, B2 -= X1 L21^T, X2 = B2 L22^-T over the two 512-column halves; the product in the middle runs
+                // on the float16 pipe from the second block column on (X1 split straight into the planes, L21 into the planes'
+                // unused rows of the diagonal block).
+                const bool h3_panel = h3 && k > 0 && nbk == nb && nb == 1024 && m - nb2 >= 2048 && NNGP_KNOB(2) != 3 &&
+                                      !(NNGP_KNOB(3) >= 10 && NNGP_KNOB(3) < 20 && k < NNGP_KNOB(3) - 10);
+                if (h3_panel) {
+                    const int64_t h = nbk / 2, mr = m - nb2;
+                    char* pk = sw->planes + (int64_t)k * sw->col_stride;        // planes of block column k, global row 0
+                    char* xrows = pk + (o + nbk + nb2) * ldp;                    // rows of the panel being solved
+                    float* b = akk + (nbk + nb2) * ld;
+                    rc = trsm_rlt_f32(b, ld, mr, akk, ld, dk, h, la->update);                                  // X1
+                    if (rc == 0) rc = launch_split_rows(b, ld, mr, h, sw->scale, xrows, ldp, la->update);
+                    if (rc == 0) rc = launch_split_rows(akk + h * ld, ld, h, h, sw->scale, pk + (o + h) * ldp, ldp, la->update);  // L21
+                    if (rc == 0)
+                        rc = launch_gemm_nt_h3(b + h, ld, xrows, pk + (o + h) * ldp, ldp, mr, h, h, -1.0f / (sw->scale * sw->scale), 1.0f,
+                                               false, 0, sw->counters, NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32, la->update);
+                    if (rc == 0) rc = trsm_rlt_f32(b + h, ld, mr, akk + h * ld + h, ld, dk + (h / TB) * TB * TB, h, la->update);  // X2
+                    if (rc == 0) rc = launch_split_rows(b + h, ld, mr, h, sw->scale, xrows + h * 4, ldp, la->update);
+                    if (rc == 0)  // the rows solved first (critical path) go into the planes as well
+                        rc = launch_split_rows(p, ld, nb2, nbk, sw->scale, pk + (o + nbk) * ldp, ldp, la->update);
+                    panel_split_done = true;
+                } else {
+                    rc = trsm_rlt_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk, la->update);
+                }
             }
             // The leading columns of the factor are large and of one sign (K is a positive kernel); the float16 MFMA
             // accumulator truncates toward zero, which biases long same-sign sums (-2.6e-8 relative at K = 1024 on
@@ -445,8 +464,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // one launch: rows [nb2, m) x columns [0, m) of the trailing matrix, on or below its diagonal
                 // (the split copy of block column k stays in place, rows at their global index: the blocked triangular
                 // solves of the posterior read it again)
-                const int64_t ldp = 4 * sw->k_cap;
-                char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
+                char* planes = pk_rows;
                 if (rc == 0 && !panel_split_done) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
                 if (rc == 0)  // columns [lead, nbk) of the panel (K blocks are walked from the high end down)
                     rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp + lead * 4, planes + lead * 4, ldp, m - nb2, m,
@@ -458,21 +476,16 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                     rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, lead,
                                             -1.0f, 1.0f, true, la->update);
             } else {
-                if (h3 && rc == 0) {  // the split copy is still needed by the posterior solves
-                    const int64_t ldp = 4 * sw->k_cap;
-                    char* planes = sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp;
-                    rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
-                }
+                if (h3 && rc == 0 && !panel_split_done)  // the split copy is still needed by the posterior solves
+                    rc = launch_split_rows(p, ld, m, nbk, sw->scale, pk_rows, ldp, la->update);
                 if (rc == 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, nbk, -1.0f, 1.0f, false, la->update);
                 if (rc == 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld + nb2, ld, p + nb2 * ld, ld, p + nb2 * ld, ld, m - nb2, m - nb2, nbk,
                                             -1.0f, 1.0f, true, la->update);
             }
-        } else if (rc == 0 && h3 && nbk == nb) {  // last panel: no trailing update left, but keep its split copy complete
-            const int64_t ldp = 4 * sw->k_cap;
-            rc = launch_split_rows(p, ld, m, nbk, sw->scale, sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp, ldp,
-                                   la->update);
+        } else if (rc == 0 && h3 && nbk == nb && !planes_here) {  // last panel: no trailing update left, but keep its split copy complete
+            rc = launch_split_rows(p, ld, m, nbk, sw->scale, pk_rows, ldp, la->update);
         }
     }
     if (rc == 0 && h3) sw->l_ready = true;
