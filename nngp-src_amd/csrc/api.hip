@@ -150,6 +150,7 @@ struct nngp_model {
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
+        dev_free(split.ldiag); dev_free(split.dfrag);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
         dev_free(ainv64);
@@ -523,6 +524,8 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         const int64_t ncols = (np + kLookAheadNb - 1) / kLookAheadNb;
         rc = dev_alloc(&m->split.planes, ncols * m->split.col_stride);
         if (rc == 0) rc = dev_alloc(&m->split.counters, 8);
+        if (rc == 0) rc = dev_alloc(&m->split.ldiag, kLookAheadNb * kLookAheadNb * 4);
+        if (rc == 0) rc = dev_alloc(&m->split.dfrag, kLookAheadNb * 128);
     }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {

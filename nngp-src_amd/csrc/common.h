@@ -22,7 +22,8 @@ void set_error(const char* fmt, ...);
 //   3  (also) 40 + e = stopping tolerance 10^-e of the early-stopped alpha CG (scripts/partial_tol_study.py)
 //   1  block-column width of the look-ahead Cholesky (default 1024)
 //   2  1 = no look-ahead (recursion on one stream); 2 = trailing updates on the float32 MFMA; 3 = panel-solve product on the
-//      float32 MFMA (trailing updates stay on the float16 pipe); 4 = round-1 panel solves (GEMM recursion instead of trsm_panel.hip)
+//      float32 MFMA (trailing updates stay on the float16 pipe); 4 = round-1 panel solves (GEMM recursion instead of trsm_panel.hip);
+//      5 = fused panel solves entirely in float32 (no float16-pipe products)
 //   3  1 = slower leaf variant; 3 = kernel build with the float64-MFMA Gram product; 10 + n = first n block columns of the
 //      Cholesky on the float32 MFMA; 20 + c = float32 lead of 128 c columns in the first trailing update (default 256)
 //   4  compute units the persistent split-float16 grid leaves free (default 32 in the Cholesky); panel CUs of the CU-mask
@@ -126,6 +127,11 @@ int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, 
 // ---- trsm_panel.hip: b [m, w] <- b L^-T in one launch (w <= 1024), optionally with the rows' float16 split copy ----
 int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t w,
                           char* planes, int64_t ldp, float scale, hipStream_t s);
+int launch_split_diag_frag(const float* a, int64_t ld, int64_t w, float scale, char* out, const float* dinv, float* dfrag,
+                           hipStream_t s);
+int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, int64_t w, char* planes,
+                         int64_t ldp, float scale, hipStream_t s);
+
 
 struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one per model
     char* planes = nullptr;    // [ncols][rows_cap][k_cap] x 4 bytes: L by block column k, row index = global row
@@ -136,6 +142,8 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
     int* counters = nullptr;   // 8 work counters of the persistent GEMM grid (one per XCD)
     bool l_ready = false;      // every block column of the current factor has been written
     int64_t split_panel = -1;  // block-column offset whose split copy was last written by the block-column ABI
+    char* ldiag = nullptr;     // 4 k_cap^2 bytes: split copy of the diagonal block being solved against, in the fragment order of k_trsm_panel_h3
+    float* dfrag = nullptr;    // k_cap x 128 floats: its inverted 128-blocks in the same fragment order
     char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)
     bool lt_ready = false;
     char* planes_b = nullptr;  // [mb_cap + 256][k_cap] x 4 bytes: the right-hand-side block of a blocked solve

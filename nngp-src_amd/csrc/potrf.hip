@@ -403,8 +403,18 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         const bool planes_here = h3 && nbk == nb && fused;
         const int64_t ldp = h3 ? 4 * sw->k_cap : 0;
         char* pk_rows = h3 ? sw->planes + (int64_t)k * sw->col_stride + (o + nbk) * ldp : nullptr;  // split copy of row o + nbk
-        if (fused)
-            rc = launch_trsm_panel_f32(akk + nbk * ld, ld, nb2, akk, ld, dk, nbk, planes_here ? pk_rows : nullptr, ldp,
+        // (One launch for ALL m rows: a separate launch for the nb2 rows the next diagonal block needs kept 32 workgroups -- an
+        // eighth of the GPU -- busy for a whole 0.14 ms workgroup round per block column, 4.4 ms per factorisation at N = 32768;
+        // the first workgroups of the merged launch are those rows anyway.)
+        // From the second block column on the solve's left-looking products run on the float16 pipe (k_trsm_panel_h3): the
+        // diagonal block is split into its own buffer first, in the order the kernel's waves read it (k_split_diag_frag).  (Block column 0 stays float32: same-sign
+        // data, see below.  Debug key 2 = 5: float32 everywhere.)
+        const bool solve_h3 = fused && planes_here && k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr && NNGP_KNOB(2) != 5;
+        if (solve_h3) {
+            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, la->update);
+            if (rc == 0) rc = launch_trsm_panel_h3(akk + nbk * ld, ld, m, sw->ldiag, sw->dfrag, nbk, pk_rows, ldp, sw->scale, la->update);
+        } else if (fused)
+            rc = launch_trsm_panel_f32(akk + nbk * ld, ld, m, akk, ld, dk, nbk, planes_here ? pk_rows : nullptr, ldp,
                                        h3 ? sw->scale : 1.0f, la->update);
         else
             rc = trsm_rlt_f32(akk + nbk * ld, ld, nb2, akk, ld, dk, nbk, la->update);
@@ -414,9 +424,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         if (rc == 0 && m > nb2) {
             panel_split_done = false;
             if (fused) {
-                rc = launch_trsm_panel_f32(akk + (nbk + nb2) * ld, ld, m - nb2, akk, ld, dk, nbk,
-                                           planes_here ? pk_rows + nb2 * ldp : nullptr, ldp, h3 ? sw->scale : 1.0f, la->update);
-                panel_split_done = planes_here;
+                panel_split_done = planes_here;  // every row was solved (and split) by the launch above
             } else {
                 // Round-1 form (debug key 2 = 4).  The solve of the remaining panel rows, X = B L_kk^-T, splits as
                 // X1 = B1 L11^-T, B2 -= X1 L21^T, X2 = B2 L22^-T over the two 512-column halves; the product in the middle runs

@@ -23,6 +23,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int PR = 32;            // rows of B per workgroup
 constexpr int PWMAX = 1024;       // widest panel
@@ -94,16 +95,16 @@ __global__ __launch_bounds__(512) void k_trsm_panel_f32(float* __restrict__ b, i
             }
         }
     };
-    // group 1 hands its partial sums to group 0 through Ls ([128 columns][32 rows], conflict-free both ways)
+    // group 1 hands its partial sums to group 0 through Ls ([32 rows][128 columns]: lanes along a row)
     auto reduce = [&](f32x16& acc) {
         if (grp == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Ls[(32 * wc + frow) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh] = acc[r];
+            for (int r = 0; r < 16; ++r) Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * 128 + 32 * wc + frow] = acc[r];
         }
         __syncthreads();
         if (grp == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += Ls[(32 * wc + frow) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+            for (int r = 0; r < 16; ++r) acc[r] += Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * 128 + 32 * wc + frow];
         }
     };
 
@@ -160,6 +161,244 @@ __global__ __launch_bounds__(512) void k_trsm_panel_f32(float* __restrict__ b, i
     }
 }
 
+
+// ---- the same solve with the left-looking products on the float16 matrix pipe --------------------------------------------
+// T = B_j - X_{<j} L[j, <j]^T is 7/9 of the solve's flops at w = 1024.  Here X_{<j} is kept in LDS as float16 hi/lo split rows
+// (the format the solved rows are written in anyway, gemm_h3.hip) and L streams in from the split copy of the diagonal block,
+// so a 32-k step costs a wave 3 v_mfma_f32_32x32x16_f16 (96 cycles) instead of 16 float32 MFMAs (1024 cycles).  The
+// multiplication by the inverted diagonal block, X_j = T dinv_j^T, which sets the accuracy of the result directly, stays
+// float32.  Operand rounding of the products: 22 significant bits, as in the trailing updates.
+#ifdef NNGP_TIMING_KNOBS
+__device__ unsigned long long g_trsm_stamps[8];
+__device__ unsigned long long g_trsm_wave[16];   // per wave of workgroup 0: cycles from block start to the end of its phase A; [8+w]: to T complete  // cycles of workgroup 0 / thread 0 per phase (timing study, knob 7 = 9)
+#define TRSM_STAMP(i) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                           atomicAdd(&g_trsm_stamps[i], now_ - last_); last_ = now_; } } while (0)
+#else
+#define TRSM_STAMP(i) do { } while (0)
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (vmcnt(0)), i.e. it
+// would wait for the NEXT block's operand loads that this kernel keeps in flight across its barriers on purpose
+// (measured: 6.3k cycles per block lost there).  Global stores need no ordering inside the kernel.
+#define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+constexpr int HXS = (PWMAX - 128) * 4 + 16;  // bytes per row of the split row block (blocks 0..6; the last block is never an operand)
+constexpr int TFS = 132;                     // floats per row of the float32 block buffer
+
+__device__ __forceinline__ int lds_off16(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+
+// Split copy of a diagonal block in the order k_trsm_panel_h3's waves consume it: for (128-row block jb, 32-k block kb, 32-row
+// group wc, k16 half g) one contiguous 2 KB piece = [64 lanes x 16 bytes of hi halfs | the same of lo halfs], lane = row % 32 +
+// 32 * (k8 group & 1) -- so that a wave's operand load is ONE fully coalesced kilobyte.  (Loading the same fragments from
+// row-major split rows costs 32 cache lines per instruction; measured 760-1480 cycles per 32-k step, TCP-bound.)
+// The same launch re-orders the inverted 128-blocks (float32) the same way: piece (jb, t, s, wc, g) = 64 lanes x 16 bytes, lane
+// (row % 32, fh) holding dinv_jb[32 wc + row % 32][(3 - t) 32 + 16 g + 8 s + 4 fh .. + 3] -- the operand of phase B.
+__global__ __launch_bounds__(256) void k_split_diag_frag(const float* __restrict__ a, int64_t ld, int w, float scale,
+                                                         char* __restrict__ out, const float* __restrict__ dinv,
+                                                         float* __restrict__ dfrag) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int k8_per_row = w >> 3;
+    const int r = idx / k8_per_row, c8 = idx - r * k8_per_row;
+    if (r >= w) return;
+    if (c8 < 16) {  // the 128 x 128 inverse of this row's diagonal block: 16 groups of 8 k per row
+        const int jb = r >> 7, cjr = r & 127, wcr = cjr >> 5, fr = cjr & 31;
+        const float* srcd = dinv + (int64_t)jb * 128 * 128 + cjr * 128 + c8 * 8;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(srcd), d1 = *reinterpret_cast<const f32x4*>(srcd + 4);
+        // k = 8 c8 + 4 fh + e  ->  t = 3 - (k >> 5), g = (k >> 4) & 1, s = (k >> 3) & 1, fh = (k >> 2) & 1
+        const int k0 = 8 * c8, t = 3 - (k0 >> 5), g = (k0 >> 4) & 1, sx = (k0 >> 3) & 1;
+        float* piece = dfrag + ((((int64_t)jb * 4 + t) * 2 + sx) * 4 + wcr) * 2 * 256 + g * 256;  // 64 lanes x 4 floats per piece
+        *reinterpret_cast<f32x4*>(piece + fr * 4) = d0;          // fh = 0
+        *reinterpret_cast<f32x4*>(piece + (32 + fr) * 4) = d1;   // fh = 1
+    }
+    const f32x4* src = reinterpret_cast<const f32x4*>(a + (int64_t)r * ld + c8 * 8);
+    const f32x4 v0 = src[0], v1 = src[1];
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (e < 4 ? v0[e] : v1[e - 4]) * scale;
+        const _Float16 h = (_Float16)x;
+        hi[e] = h;
+        lo[e] = (_Float16)(x - (float)h);
+    }
+    const int jb = r >> 7, wc = (r >> 5) & 3, frow = r & 31;
+    const int kb = c8 >> 2, within = c8 & 3, g = within >> 1, fh = within & 1;
+    const int64_t piece = ((((int64_t)jb * (w >> 5) + kb) * 4 + wc) * 2 + g) * 2048;
+    char* dst = out + piece + (frow + 32 * fh) * 16;
+    *reinterpret_cast<h8*>(dst) = hi;
+    *reinterpret_cast<h8*>(dst + 1024) = lo;
+}
+
+__global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, int64_t ldb, const char* __restrict__ lsplit,
+                                                       const float* __restrict__ dinv, int w, char* __restrict__ planes,
+                                                       int64_t ldp, float scale) {
+    __shared__ __attribute__((aligned(16))) char Xp[PR * HXS];     // solved blocks, split rows: [row][k / 32][32 hi | 32 lo]
+    __shared__ __attribute__((aligned(16))) float Tf[PR * TFS];    // current block in float32: B_j, then T, then X_j
+    __shared__ __attribute__((aligned(16))) float Lf[PR * TFS];    // partial sums of wave group 1, laid out like Tf (lanes along a row:
+                                                                   // [column][row] put all 32 lanes of a store on two banks)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wc = wave & 3;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * PR;
+    float* bg = b + row0 * ldb;
+    const float inv_s2 = 1.0f / (scale * scale);
+    const int crow = tid >> 4, cc8 = tid & 15;  // this thread's (row, group of 8 columns) in the cooperative passes
+    const int cj = 32 * wc + frow;              // this lane's output column inside a 128-column block = its row of L / dinv
+    // A wave's B operand is private to it (rows 32 wc .. 32 wc + 31 of the L / dinv block, the k16 half `grp`): it is loaded
+    // straight from L2 into registers, four k-blocks ahead, with no LDS staging and NO workgroup barrier inside the products --
+    // the staged form (a barrier pair and an exposed L2 round trip per 32-k step) ran 115 us per workgroup for 10 us of MFMAs.
+    const int chi = (grp * 2 + fh) * 16, clo = (4 + grp * 2 + fh) * 16;  // this lane's hi / lo chunk inside a 128-byte k-block of Xp
+    const int nkb = w >> 5;                                              // k-blocks per row of the diagonal block
+
+    const int nblk = w / 128;
+    // Operands of block j + 1 that do not depend on block j -- its rows of B, this wave's part of dinv_{j+1}, the first group of
+    // L[j+1, :] fragments -- are requested while block j is still being finished, so that no L2 round trip sits between blocks.
+    f32x4 b0, b1, dv[4][2];
+    h8 nh[4], nl[4], nh2[4], nl2[4];  // L fragments one and two groups (of four 32-k blocks) ahead of the MFMAs
+    auto load_block_inputs = [&](int jj) {
+        b0 = *reinterpret_cast<const f32x4*>(bg + (int64_t)crow * ldb + 128 * jj + 8 * cc8);
+        b1 = *reinterpret_cast<const f32x4*>(bg + (int64_t)crow * ldb + 128 * jj + 8 * cc8 + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+                dv[t][sidx] = *reinterpret_cast<const f32x4*>(dinv + (((((int64_t)jj * 4 + t) * 2 + sidx) * 4 + wc) * 2 + grp) * 256 + lane * 4);
+    };
+    // fragments of L[jj, :] for k-blocks kb_hi .. kb_hi - 3 (k_split_diag_frag order) into (dh, dl)
+    auto load_group = [&](h8 (&dh)[4], h8 (&dl)[4], int jj, int kb_hi) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const char* piece = lsplit + ((((int64_t)jj * nkb + (kb_hi - u)) * 4 + wc) * 2 + grp) * 2048 + lane * 16;
+            dh[u] = *reinterpret_cast<const h8*>(piece);
+            dl[u] = *reinterpret_cast<const h8*>(piece + 1024);
+        }
+    };
+    load_block_inputs(0);
+#ifdef NNGP_TIMING_KNOBS
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (int j = 0; j < nblk; ++j) {
+#ifdef NNGP_TIMING_KNOBS
+        const unsigned long long wstart_ = __builtin_amdgcn_s_memtime();
+#endif
+        const f32x4 cb0 = b0, cb1 = b1;
+        f32x4 cdv[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) cdv[t][sidx] = dv[t][sidx];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // ---- phase A: acc = X_{<j} L[j, <j]^T (times scale^2), split operands, k-blocks from the high end down ----
+        if (j > 0) {
+            const int nk = 4 * j;
+            for (int g = 0; g < j; ++g) {
+                h8 ch[4], cl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ch[u] = nh[u]; cl[u] = nl[u]; nh[u] = nh2[u]; nl[u] = nl2[u]; }
+                // two groups ahead: an L2 miss on the freshly written split copy costs ~1500 cycles, a group of MFMAs ~600
+                if (g + 2 < j) load_group(nh2, nl2, j, nk - 1 - 4 * (g + 2));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const char* xa = Xp + frow * HXS + (nk - 1 - 4 * g - u) * 128;
+                    const h8 ah = *reinterpret_cast<const h8*>(xa + chi);
+                    const h8 al = *reinterpret_cast<const h8*>(xa + clo);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cl[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ch[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch[u], acc, 0, 0, 0);
+                }
+            }
+        }
+        TRSM_STAMP(0);  // phase A
+#ifdef NNGP_TIMING_KNOBS
+        if (blockIdx.x == 0 && lane == 0) atomicAdd(&g_trsm_wave[wave], __builtin_amdgcn_s_memtime() - wstart_);
+#endif
+        if (j + 1 < nblk) {  // the next block's inputs, in flight through the rest of this block
+            load_block_inputs(j + 1);
+            load_group(nh, nl, j + 1, 4 * (j + 1) - 1);
+            if (j + 1 >= 2) load_group(nh2, nl2, j + 1, 4 * (j + 1) - 5);
+        }
+        // B_j into Tf (Tf was drained by the previous block's write-out; no one reads it before the barrier below)
+        *reinterpret_cast<f32x4*>(&Tf[crow * TFS + 8 * cc8]) = cb0;
+        *reinterpret_cast<f32x4*>(&Tf[crow * TFS + 8 * cc8 + 4]) = cb1;
+        if (j > 0) {
+            if (grp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Lf[((r & 3) + 8 * (r >> 2) + 4 * fh) * TFS + cj] = acc[r];
+            }
+            LDS_BARRIER();
+            if (grp == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    Tf[row * TFS + cj] -= (acc[r] + Lf[row * TFS + cj]) * inv_s2;
+                }
+            }
+        }
+        LDS_BARRIER();  // T complete
+        TRSM_STAMP(1);  // B_j wait + reduce + T
+#ifdef NNGP_TIMING_KNOBS
+        if (blockIdx.x == 0 && lane == 0) atomicAdd(&g_trsm_wave[8 + wave], __builtin_amdgcn_s_memtime() - wstart_);
+#endif
+        // ---- phase B: X_j = T dinv_j^T in float32 (split-K over the two wave groups), dinv fragments already in registers ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k0 = (3 - t) * 32 + 16 * grp;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(&Tf[frow * TFS + k0 + (2 * sidx + fh) * 4]);
+                const f32x4 fb = cdv[t][sidx];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+            }
+        }
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Lf[((r & 3) + 8 * (r >> 2) + 4 * fh) * TFS + cj] = acc[r];
+        }
+        TRSM_STAMP(2);  // phase B MFMAs
+        LDS_BARRIER();  // group 1's sums are in place AND every wave has finished reading T
+        if (grp == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                Tf[row * TFS + cj] = acc[r] + Lf[row * TFS + cj];
+            }
+        }
+        LDS_BARRIER();
+        TRSM_STAMP(3);  // reduce + X
+        // ---- X_j out: float32 rows, their split copy in global memory, and the split copy in LDS for the later blocks ----
+        {
+            const int kq = 128 * j + 8 * cc8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Tf[crow * TFS + 8 * cc8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Tf[crow * TFS + 8 * cc8 + 4]);
+            float* dst = bg + (int64_t)crow * ldb + kq;
+            *reinterpret_cast<f32x4*>(dst) = v0;
+            *reinterpret_cast<f32x4*>(dst + 4) = v1;
+            h8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float a = (q < 4 ? v0[q] : v1[q - 4]) * scale;
+                const _Float16 h = (_Float16)a;
+                hi[q] = h;
+                lo[q] = (_Float16)(a - (float)h);
+            }
+            const int off = (kq >> 5) * 128 + ((kq & 31) >> 3) * 16;
+            if (planes != nullptr) {
+                char* pd = planes + (row0 + crow) * ldp + off;
+                *reinterpret_cast<h8*>(pd) = hi;
+                *reinterpret_cast<h8*>(pd + 64) = lo;
+            }
+            if (j + 1 < nblk) {
+                *reinterpret_cast<h8*>(Xp + crow * HXS + off) = hi;
+                *reinterpret_cast<h8*>(Xp + crow * HXS + off + 64) = lo;
+            }
+        }
+        LDS_BARRIER();  // Tf, Lf and Xp settled before the next block reads / overwrites them
+        TRSM_STAMP(4);  // write-out
+    }
+}
+
 }  // namespace
 
 // b [m, w] <- b * L^-T for the w x w lower block at `l` with its inverted 128-blocks `dinv` (w/128 blocks of 128 x 128).
@@ -179,4 +418,50 @@ int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int6
     return 0;
 }
 
+}  // namespace nngp
+
+namespace nngp {
+// Split copy of the w x w diagonal block at `a` in the fragment order of k_trsm_panel_h3 (4 w^2 bytes at `out`).
+int launch_split_diag_frag(const float* a, int64_t ld, int64_t w, float scale, char* out, const float* dinv, float* dfrag,
+                           hipStream_t s) {
+    NNGP_REQUIRE(w > 0 && w % 128 == 0 && w <= PWMAX && ld % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+                     dinv != nullptr && dfrag != nullptr && ((uintptr_t)dinv & 15) == 0 && ((uintptr_t)dfrag & 15) == 0,
+                 "split_diag_frag: w must be a multiple of 128 up to 1024, operands 16-byte aligned");
+    const int64_t total = w * (w / 8);
+    hipLaunchKernelGGL(k_split_diag_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ld, (int)w, scale, out, dinv, dfrag);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// b [m, w] <- b * L^-T with the left-looking products on the float16 pipe.  lfrag: launch_split_diag_frag of the diagonal block
+// (same scale) -- only its strictly lower 128-blocks are read; dfrag: the inverted 128-blocks in the order the same launch wrote them.
+int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, int64_t w, char* planes,
+                         int64_t ldp, float scale, hipStream_t s) {
+    if (m <= 0 || w <= 0) return 0;
+    NNGP_REQUIRE(m % PR == 0 && w % 128 == 0 && w <= PWMAX, "trsm_panel_h3: m must be a multiple of 32, w of 128 and <= 1024");
+    NNGP_REQUIRE(ldb % 4 == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)dinv & 15) == 0 && lfrag != nullptr &&
+                     ((uintptr_t)lfrag & 15) == 0 && ldp % 16 == 0 && ldp >= 4 * w && scale > 0.0f,
+                 "trsm_panel_h3: operands must be 16-byte aligned with ldp >= 4 w");
+    NNGP_REQUIRE(planes == nullptr || ((uintptr_t)planes & 15) == 0, "trsm_panel_h3: split rows must be 16-byte aligned");
+    hipLaunchKernelGGL(k_trsm_panel_h3, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, lfrag, dinv, (int)w, planes, ldp, scale);
+    NNGP_HIP_CHECK(hipGetLastError());
+#ifdef NNGP_TIMING_KNOBS
+    if (NNGP_KNOB(7) == 9) {  // timing study: cycles of workgroup 0 per phase, summed over the launches so far
+        unsigned long long h[8];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trsm_stamps), sizeof(h)) == hipSuccess)
+            fprintf(stderr, "trsm_panel_h3 stamps (m=%lld): phaseA %llu  wait+reduce+T %llu  phaseB %llu  reduce+X %llu  writeout %llu\n",
+                    (long long)m, h[0], h[1], h[2], h[3], h[4]);
+        unsigned long long hw[16];
+        if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_trsm_wave), sizeof(hw)) == hipSuccess) {
+            fprintf(stderr, "   per wave, block start -> end of phase A:");
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", hw[i]);
+            fprintf(stderr, "\n   per wave, block start -> T complete:");
+            for (int i = 8; i < 16; ++i) fprintf(stderr, " %llu", hw[i]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    return 0;
+}
 }  // namespace nngp
