@@ -28,7 +28,7 @@ def timeit(fn, reps=5, warm=2):
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load(knobs=True)
     dev = G.dev()
     out = {}
     torch.manual_seed(0)
