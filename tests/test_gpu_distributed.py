@@ -109,3 +109,49 @@ def test_native_rccl_communicator_single_rank():
     lib = _lib.load()
     assert lib.nngp_bcast(_lib.ptr(v), 33, _lib.DTYPE_F32, 3, comm.handle, None) != 0  # root outside the communicator
     comm.close()
+
+
+def _worker2d(rank, world, port, pr, pc, n, d, nb, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nngp_src_amd import dist2d, synth
+        x, y = synth.synthetic_queries(n, d, seed=0)
+        xt, _ = synth.synthetic_queries(70, d, seed=1)
+        grid = dist2d.Grid(pr, pc)
+        gp = dist2d.Dist2DGP(dist2d.HipOps([1.0, 1.0], [0.0, 0.0]), grid, x, y, diag_reg=1e-3, nb=nb).fit()
+        nbk = (n + nb - 1) // nb
+        assert gp.a32.shape == (len(range(grid.pr, nbk, pr)) * nb, len(range(grid.pc, nbk, pc)) * nb)  # its tiles only
+        assert gp.clamped == 0 and gp.relres < 1e-10, (gp.clamped, gp.relres, gp.cg_iters)
+        mean, var = gp.predict(xt)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean, var=var, alpha=gp.alpha.cpu().numpy(), iters=gp.cg_iters)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb", [(2, 2, 2100, 256), (2, 1, 1300, 512)])
+def test_2d_block_cyclic_fit_on_the_gpu_matches_single_gpu(tmp_path, pr, pc, n, nb):
+    """the 2-D block-cyclic distributed fit (nngp-src_amd/dist2d.py) with the HIP kernels doing the tile
+    work -- kernel build of the rank's own tiles, leaf Cholesky + inverse, float32 and float64 MFMA GEMMs -- and gloo doing
+    the collectives between ranks that share the test box's one GPU.  No rank holds the whole kernel or factor; alpha, means
+    and level-1 variances must agree with the single-GPU model."""
+    d, world = 24, pr * pc
+    sys.path.insert(0, ROOT)
+    from nngp_src_amd import synth
+    from nngp_src_amd.model import GPModel
+    mp.spawn(_worker2d, args=(world, _free_port(), pr, pc, n, d, nb, str(tmp_path)), nprocs=world, join=True)
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(70, d, seed=1)
+    ref = GPModel(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    m0, v0 = ref.predict(xt, cov="diag")
+    a0 = ref.alpha().cpu().numpy().ravel()
+    for r in range(world):
+        g = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.linalg.norm(g["alpha"] - a0) / np.linalg.norm(a0) < 1e-7
+        assert np.linalg.norm(g["mean"] - m0.ravel()) / np.linalg.norm(m0) < 1e-8
+        np.testing.assert_allclose(g["var"], v0, rtol=1e-4)
