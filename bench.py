@@ -106,14 +106,60 @@ def cpu_baseline(n_bench, d, m, n_relu, gpu_ms):
     return out
 
 
+def bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, m, desc):
+    """Opt-in comparison layout: the 2-D block-cyclic fit of nngp-src_amd/dist2d.py.  A step = build of the
+    rank's own tiles + distributed Cholesky + distributed CG for alpha + mean and level-1 variance of the test queries (replicated
+    right-hand-side blocks of 128).  Correctness-first code: one float32 GEMM per trailing update, torch glue between kernels."""
+    import torch
+    import torch.distributed as dist
+    from nngp_src_amd import dist2d
+    pr = int(os.environ.get("NNGP_GRID_ROWS", "0")) or max(p for p in range(1, int(world ** 0.5) + 1) if world % p == 0)
+    pc = world // pr
+    grid = dist2d.Grid(pr, pc)
+    ops = dist2d.HipOps([1.0] * (n_relu + 1), [0.0] * (n_relu + 1), get=get)
+    mt = min(m, int(os.environ.get("NNGP_GRID_TEST_ROWS", "128")))
+
+    def step():
+        gp = dist2d.Dist2DGP(ops, grid, x, y, diag_reg=1e-3, nb=1024).fit()
+        gp.predict(xt[:mt])
+        return gp
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gp = step()
+    dist.barrier(); torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        fl = flop_model(n, d, mt, n_relu)
+        ms = float(t.item()) / args.steps * 1e3
+        print(json.dumps({
+            "metric": "NNGP kernel-build + GP-solve wall-clock (ms) and GFLOP/s at N train queries",
+            "value": round(fl["total"] / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (tile Cholesky and updates on the float32 MFMA; f64 build/CG/means)", "data": "synthetic",
+            "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": mt,
+                       "parallelism": "2-D block-cyclic %d x %d (tiles of 1024): no rank holds the whole kernel or factor; panel broadcasts "
+                                      "along process rows, exchanges inside process columns, fan-in triangular solves" % (pr, pc)},
+            "fit_info": {"cg_iters": gp.cg_iters, "rel_residual": gp.relres, "clamped_pivots": gp.clamped, "reg": gp.reg,
+                         "alpha_l2": float(torch.linalg.vector_norm(gp.alpha).item())},
+            "shard": {"ranks_seen": dist.get_world_size(), "local_tile_bytes": int(gp.a32.numel() * 4 + gp.k64t.numel() * 8)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg3 on one GPU, cfg4 on several")
-    ap.add_argument("--mode", default=os.environ.get("NNGP_DIST_MODE", "shard"), choices=["shard", "replicate"],
-                    help="multi-GPU layout (default: the north star's row-block shard + all-gather)")
+    ap.add_argument("--mode", default=os.environ.get("NNGP_DIST_MODE", "shard"), choices=["shard", "replicate", "grid2d"],
+                    help="multi-GPU layout (default: the north star's row-block shard + all-gather; grid2d: the 2-D block-cyclic "
+                         "fit of dist2d.py, no rank holding the whole kernel or factor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compare", action="store_true", help="multi-GPU: skip the untimed comparison legs")
     args = ap.parse_args()
@@ -152,6 +198,8 @@ def main():
     n, d, n_relu, get, m, join_block, desc = CONFIGS[cfg_name]
     x, y = synth.synthetic_queries(n, d, seed=0, join_block=join_block)
     xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
+    if world > 1 and args.mode == "grid2d":
+        return bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, m, desc)
     xd, yd, xtd = (torch.from_numpy(a).to(dev) for a in (x, y, xt))
     m0, m1 = distributed.row_partition(m, world, rank)
     xt_local = xtd[m0:m1].contiguous()
