@@ -14,6 +14,7 @@
 // 32x32 inverses by block forward substitution on the matrix cores.  LDS row stride is 129 floats, which
 // makes row-wise and column-wise 4-byte fragment reads conflict free.
 #include <atomic>
+#include <cstdio>
 #include <new>
 
 #include "common.h"
@@ -232,10 +233,250 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(float* A, int64_t ld, float*
     if (wave == 0 && lane == 0 && nclamp > 0 && clamped != nullptr) atomicAdd(clamped, nclamp);
 }
 
+// Panel form of the leaf (the product path; k_potrf_leaf above is kept for A/B timing, debug key 3 = 2).  In k_potrf_leaf
+// three of the four waves idle while wave 0 factors AND inverts each 32x32 diagonal sub-block (two dependent 32-step passes,
+// ~8 of the ~11 us a sub-block column takes), and the sub-blocks below wait for that inverse.  Here the wave that owns block
+// row w eliminates its 32 rows against the diagonal sub-block's columns AS the leader (wave jb) produces them: the leader
+// publishes column j of the diagonal sub-block in an LDS ring and bumps a step counter, the followers poll the counter and
+// apply the same rank-1 step to their own rows (LDS operations of one wave execute in order, so the counter is visible after
+// the column; no barrier inside the 32 steps).  The sub-blocks below are therefore solved by substitution when the leader
+// finishes -- no inverse on the critical path -- and the four diagonal inverses are computed at the end, one per wave, in
+// parallel.  Critical path per sub-block column: one 32-step pass + the MFMA updates.
+#ifdef NNGP_TIMING_KNOBS
+__device__ unsigned long long g_leaf_stamps[4 * 16];  // per wave: cycles from kernel start to the end of each phase (debug key 7 = 8)
+#define LEAF_STAMP(idx) do { if (lane == 0) g_leaf_stamps[wave * 16 + (idx)] = __builtin_amdgcn_s_memtime() - t_start_; } while (0)
+#else
+#define LEAF_STAMP(idx) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, float* dinv, int32_t* clamped,
+                                                             float pivot_floor) {
+    __shared__ float Lb[10 * BLK];
+    __shared__ float Xb[10 * BLK];
+    __shared__ float Tb[3 * BLK];   // scratch of the inverse assembly (one block per active wave)
+    __shared__ float ring[16 * 64];  // line j/2: columns j and j+1 of the current diagonal sub-block before elimination step j
+    __shared__ int step_flag;        // column pairs published so far: 16 jb + j/2 + 1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = tid >> 3, lc = (tid & 7) * 4;  // this thread's (row, first column) inside a 32x32 sub-block
+    if (tid == 0) step_flag = 0;
+#ifdef NNGP_TIMING_KNOBS
+    const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        float4 v[10];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb <= ib; ++jb)
+                v[blk(ib, jb)] = *reinterpret_cast<const float4*>(A + (int64_t)(ib * 32 + lr) * ld + jb * 32 + lc);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb <= ib; ++jb) {
+                const float4 t = v[blk(ib, jb)];
+                float* lp = Lb + blk(ib, jb) * BLK + lr * LS + lc;
+                float* xp = Xb + blk(ib, jb) * BLK + lr * LS + lc;
+                const bool diag = (ib == jb);  // strictly-upper entries of a diagonal sub-block are not part of A
+                lp[0] = (!diag || lc + 0 <= lr) ? t.x : 0.0f;
+                lp[1] = (!diag || lc + 1 <= lr) ? t.y : 0.0f;
+                lp[2] = (!diag || lc + 2 <= lr) ? t.z : 0.0f;
+                lp[3] = (!diag || lc + 3 <= lr) ? t.w : 0.0f;
+                xp[0] = xp[1] = xp[2] = xp[3] = 0.0f;
+            }
+    }
+    __syncthreads();
+    LEAF_STAMP(0);
+
+    int nclamp = 0;
+    const int i = lane & 31;
+    float a[32], pinv[32];  // this lane's row of block (wave, jb); pinv[j] = 1 / L[j][j] of the sub-block this wave led
+#pragma unroll 1
+    for (int jb = 0; jb < 4; ++jb) {
+        if (wave >= jb) {
+            const bool leader = (wave == jb);
+            float* Bw = Lb + blk(wave, jb) * BLK;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a[k] = Bw[i * LS + k];
+            // Two columns per LDS round trip (the round trip, ~300 cycles with its issue, is what a step costs): the leader
+            // publishes columns j and j+1 as they are BEFORE step j; every lane applies step j to its copy of column j+1 itself
+            // (one more FMA per element) and then both rank-1 updates to its own row.
+#pragma unroll
+            for (int j = 0; j < 32; j += 2) {
+                float* cA = ring + (j >> 1) * 64;  // column j,   rows >= j valid
+                float* cB = cA + 32;               // column j+1, rows >= j+1 valid (not yet updated by column j)
+                const int target = jb * 16 + (j >> 1) + 1;
+                float d0, c10, b11;
+                if (leader) {
+                    // plain LDS stores kept in program order by the compiler barriers: the LDS executes one wave's operations
+                    // in order, and `volatile` would make hipcc wait for each of them (770 instead of ~300 cycles a step)
+                    if (lane < 32) {
+                        cA[i] = a[j];
+                        cB[i] = a[j + 1];
+                    }
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) step_flag = target;
+                    asm volatile("" ::: "memory");
+                    // the leader's own pivots: no LDS round trip in front of the rsq chain
+                    d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j));
+                    c10 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j + 1));
+                    b11 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j + 1]), j + 1));
+                } else {
+                    while (__hip_atomic_load(&step_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {}
+                    asm volatile("" ::: "memory");
+                    d0 = cA[j];
+                    c10 = cA[j + 1];
+                    b11 = cB[j + 1];
+                }
+                asm volatile("" : "+v"(d0), "+v"(c10), "+v"(b11));  // keep wave-uniform values in VGPRs (no SGPR spills / readlane traffic)
+                // the columns are requested before the rsq chain below, not behind it
+                float ck0[32], ck1[32];
+#pragma unroll
+                for (int k = j + 2; k < 32; ++k) {
+                    ck0[k] = cA[k];
+                    ck1[k] = cB[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(d0 > pivot_floor)) {
+                    d0 = pivot_floor > 0.0f ? pivot_floor : 1.0e-30f;
+                    if (leader) ++nclamp;
+                }
+                float inv0 = __builtin_amdgcn_rsqf(d0);  // v_rsq_f32, ~1 ulp: ample for a preconditioner
+                asm volatile("" : "+v"(inv0));
+                const float l10 = c10 * inv0;            // L[j+1][j]
+                const float u10 = -l10 * inv0;           // column j+1 after step j: cB[k] + u10 * cA[k]
+                float d1 = fmaf(u10, c10, b11);          // = A[j+1][j+1] - L[j+1][j]^2
+                if (!(d1 > pivot_floor)) {
+                    d1 = pivot_floor > 0.0f ? pivot_floor : 1.0e-30f;
+                    if (leader) ++nclamp;
+                }
+                float inv1 = __builtin_amdgcn_rsqf(d1);
+                asm volatile("" : "+v"(inv1));
+                pinv[j] = inv0;
+                pinv[j + 1] = inv1;
+                const float lij0 = a[j] * inv0;              // L[row][j]
+                const float t0 = -lij0 * inv0;
+                a[j] = (leader && i == j) ? d0 * inv0 : lij0;
+                const float aj1 = fmaf(t0, c10, a[j + 1]);   // own entry of column j+1 after step j
+                const float lij1 = aj1 * inv1;               // L[row][j+1]
+                const float t1 = -lij1 * inv1;
+                a[j + 1] = (leader && i == j + 1) ? d1 * inv1 : lij1;
+#pragma unroll
+                for (int k = j + 2; k < 32; ++k) {
+                    const float c1 = fmaf(u10, ck0[k], ck1[k]);
+                    a[k] = fmaf(t1, c1, fmaf(t0, ck0[k], a[k]));
+                }
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) Bw[i * LS + k] = (!leader || k <= i) ? a[k] : 0.0f;
+            }
+        }
+        LEAF_STAMP(1 + 2 * jb);
+        __syncthreads();
+        // ---- trailing sub-blocks: A[ib][kb] -= A[ib][jb] * A[kb][jb]^T, jb < kb <= ib ----
+        {
+            int cnt = 0;
+            for (int ib = jb + 1; ib < 4; ++ib)
+                for (int kb = jb + 1; kb <= ib; ++kb, ++cnt) {
+                    if ((cnt & 3) != wave) continue;
+                    float* Cik = Lb + blk(ib, kb) * BLK;
+                    f32x16 acc = blk_load(Cik, lane);
+                    acc = blk_mma<false>(Lb + blk(ib, jb) * BLK, Lb + blk(kb, jb) * BLK, acc, -1.0f, lane);
+                    blk_store(Cik, acc, lane);
+                }
+        }
+        __syncthreads();
+        LEAF_STAMP(2 + 2 * jb);
+    }
+
+    // ---- the four diagonal inverses, one per wave: lane c owns column c of X = L^-1 ----
+    {
+        const float* Djj = Lb + blk(wave, wave) * BLK;
+        float* Xjj = Xb + blk(wave, wave) * BLK;
+        float x[32];
+#pragma unroll
+        for (int ii = 0; ii < 32; ++ii) {
+            float s0 = 0.0f, s1 = 0.0f;  // two chains: the sum is latency-, not throughput-bound
+#pragma unroll
+            for (int k = 0; k + 1 < ii; k += 2) {
+                s0 = fmaf(Djj[ii * LS + k], x[k], s0);  // broadcast LDS reads
+                s1 = fmaf(Djj[ii * LS + k + 1], x[k + 1], s1);
+            }
+            if (ii & 1) s0 = fmaf(Djj[ii * LS + ii - 1], x[ii - 1], s0);
+            x[ii] = (((i == ii) ? 1.0f : 0.0f) - (s0 + s1)) * pinv[ii];
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) Xjj[k * LS + i] = x[k];  // X[k][c = i]
+        }
+    }
+    LEAF_STAMP(9);
+    __syncthreads();
+
+    // ---- assemble the 128x128 inverse: X[ib][jb] = -Dinv_ii * sum_{k=jb}^{ib-1} L[ib][k] X[k][jb] ----
+#pragma unroll 1
+    for (int dist = 1; dist < 4; ++dist) {
+        const int ib = dist + wave, jb = wave;  // wave w owns block (dist + w, w)
+        const bool active = ib < 4;
+        float* scratch = Tb + (wave < 3 ? wave : 0) * BLK;
+        if (active) {
+            f32x16 t = zero16();
+            for (int k = jb; k < ib; ++k)
+                t = blk_mma<true>(Lb + blk(ib, k) * BLK, Xb + blk(k, jb) * BLK, t, 1.0f, lane);
+            blk_store(scratch, t, lane);
+        }
+        __syncthreads();
+        if (active) {
+            f32x16 xr = blk_mma<true>(Xb + blk(ib, ib) * BLK, scratch, zero16(), -1.0f, lane);
+            blk_store(Xb + blk(ib, jb) * BLK, xr, lane);
+        }
+        __syncthreads();
+    }
+
+    LEAF_STAMP(10);
+    // ---- write back: L into the lower triangle of A, X (with its zero upper blocks) into dinv ----
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+        const int ib = b >> 2, jb = b & 3;
+        float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jb <= ib) {
+            const float* lp = Lb + blk(ib, jb) * BLK + lr * LS + lc;
+            const float* xp = Xb + blk(ib, jb) * BLK + lr * LS + lc;
+            xo = make_float4(xp[0], xp[1], xp[2], xp[3]);
+            float* ap = A + (int64_t)(ib * 32 + lr) * ld + jb * 32 + lc;
+            if (ib != jb || lc + 3 <= lr) {
+                *reinterpret_cast<float4*>(ap) = make_float4(lp[0], lp[1], lp[2], lp[3]);
+            } else {  // the 4-wide group straddles or lies above the diagonal: keep the caller's upper entries
+                for (int k = 0; k < 4; ++k)
+                    if (lc + k <= lr) ap[k] = lp[k];
+            }
+        }
+        *reinterpret_cast<float4*>(dinv + (ib * 32 + lr) * 128 + jb * 32 + lc) = xo;
+    }
+    if (lane == 0 && nclamp > 0 && clamped != nullptr) atomicAdd(clamped, nclamp);
+    LEAF_STAMP(11);
+}
+
 }  // namespace
 
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s) {
-    if (NNGP_KNOB(3) != 1)  // variant 1 (scalarised broadcasts) measured 57 us vs 84 us for variant 0
+    if (NNGP_KNOB(3) != 1 && NNGP_KNOB(3) != 2)
+    {
+        hipLaunchKernelGGL(k_potrf_leaf_panel, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor);
+#ifdef NNGP_TIMING_KNOBS
+        if (NNGP_KNOB(7) == 8) {  // timing study: per wave, cycles from kernel start to the end of each phase
+            unsigned long long h[64];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_leaf_stamps), sizeof(h)) == hipSuccess)
+                for (int w = 0; w < 4; ++w) {
+                    fprintf(stderr, "leaf wave %d: load %llu |", w, h[w * 16]);
+                    for (int jb = 0; jb < 4; ++jb) fprintf(stderr, " F%d %llu U%d %llu |", jb, h[w * 16 + 1 + 2 * jb], jb, h[w * 16 + 2 + 2 * jb]);
+                    fprintf(stderr, " inv %llu asm %llu wb %llu\n", h[w * 16 + 9], h[w * 16 + 10], h[w * 16 + 11]);
+                }
+        }
+#endif
+    }
+    else if (NNGP_KNOB(3) != 1)  // variant 1 (scalarised broadcasts) measured 57 us vs 84 us for variant 0
         hipLaunchKernelGGL(k_potrf_leaf<1>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, NNGP_KNOB(0));
     else
         hipLaunchKernelGGL(k_potrf_leaf<0>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor, NNGP_KNOB(0));
