@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
     __shared__ float Lb[10 * BLK];
     __shared__ float Xb[10 * BLK];
     __shared__ float Tb[3 * BLK];   // scratch of the inverse assembly (one block per active wave)
-    __shared__ float ring[16 * 64];  // line j/2: columns j and j+1 of the current diagonal sub-block before elimination step j
+    __shared__ float ring[16 * 64];  // line j/2: columns j and j+1 of the current diagonal sub-block before elimination step j (layout: see rd)
     __shared__ int step_flag;        // column pairs published so far: 16 jb + j/2 + 1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,53 +288,54 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
     LEAF_STAMP(0);
 
     int nclamp = 0;
-    const int i = lane & 31;
-    float a[32], pinv[32];  // this lane's row of block (wave, jb); pinv[j] = 1 / L[j][j] of the sub-block this wave led
+    const int i = lane & 31, h = lane >> 5;
+    // Lane (i, h) owns the entries of row i in the columns of parity h: b[m] = entry (i, 2m + h) of block (wave, jb) -- the two
+    // half-waves split the rank-1 updates between them instead of duplicating them.
+    float b[16], pinv[32];  // pinv[j] = 1 / L[j][j] of the sub-block this wave led
+    const float* rd = ring + h * 32;  // a column pair is stored by row parity: entry (k, A|B) at ((k & 1) * 16 + (k >> 1)) * 2 + (A: 0, B: 1)
 #pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
         if (wave >= jb) {
             const bool leader = (wave == jb);
             float* Bw = Lb + blk(wave, jb) * BLK;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) a[k] = Bw[i * LS + k];
+            for (int m = 0; m < 16; ++m) b[m] = Bw[i * LS + 2 * m + h];
             // Two columns per LDS round trip (the round trip, ~300 cycles with its issue, is what a step costs): the leader
             // publishes columns j and j+1 as they are BEFORE step j; every lane applies step j to its copy of column j+1 itself
-            // (one more FMA per element) and then both rank-1 updates to its own row.
+            // (one more FMA per element) and then both rank-1 updates to its own entries.
 #pragma unroll
-            for (int j = 0; j < 32; j += 2) {
-                float* cA = ring + (j >> 1) * 64;  // column j,   rows >= j valid
-                float* cB = cA + 32;               // column j+1, rows >= j+1 valid (not yet updated by column j)
-                const int target = jb * 16 + (j >> 1) + 1;
+            for (int p = 0; p < 16; ++p) {
+                const int j = 2 * p;
+                float* line = ring + p * 64;
+                const int target = jb * 16 + p + 1;
                 float d0, c10, b11;
                 if (leader) {
                     // plain LDS stores kept in program order by the compiler barriers: the LDS executes one wave's operations
                     // in order, and `volatile` would make hipcc wait for each of them (770 instead of ~300 cycles a step)
-                    if (lane < 32) {
-                        cA[i] = a[j];
-                        cB[i] = a[j + 1];
-                    }
+                    line[((i & 1) * 16 + (i >> 1)) * 2 + h] = b[p];  // half 0: column j, half 1: column j+1 (rows >= j valid)
                     asm volatile("" ::: "memory");
                     if (lane == 0) step_flag = target;
                     asm volatile("" ::: "memory");
                     // the leader's own pivots: no LDS round trip in front of the rsq chain
-                    d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j));
-                    c10 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j + 1));
-                    b11 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j + 1]), j + 1));
+                    d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b[p]), j));
+                    c10 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b[p]), j + 1));
+                    b11 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b[p]), 32 + j + 1));
                 } else {
                     while (__hip_atomic_load(&step_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {}
                     asm volatile("" ::: "memory");
-                    d0 = cA[j];
-                    c10 = cA[j + 1];
-                    b11 = cB[j + 1];
+                    d0 = line[p * 2];              // (k = j,   A)
+                    c10 = line[(16 + p) * 2];      // (k = j+1, A)
+                    b11 = line[(16 + p) * 2 + 1];  // (k = j+1, B)
                 }
                 asm volatile("" : "+v"(d0), "+v"(c10), "+v"(b11));  // keep wave-uniform values in VGPRs (no SGPR spills / readlane traffic)
                 // the columns are requested before the rsq chain below, not behind it
-                float ck0[32], ck1[32];
+                float ck0[16], ck1[16];
 #pragma unroll
-                for (int k = j + 2; k < 32; ++k) {
-                    ck0[k] = cA[k];
-                    ck1[k] = cB[k];
+                for (int m = p + 1; m < 16; ++m) {
+                    ck0[m] = rd[p * 64 + 2 * m];
+                    ck1[m] = rd[p * 64 + 2 * m + 1];
                 }
+                const float other = __shfl_xor(b[p], 32);  // half 0 gets its row's entry of column j+1, half 1 that of column j
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(d0 > pivot_floor)) {
                     d0 = pivot_floor > 0.0f ? pivot_floor : 1.0e-30f;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
                 float inv0 = __builtin_amdgcn_rsqf(d0);  // v_rsq_f32, ~1 ulp: ample for a preconditioner
                 asm volatile("" : "+v"(inv0));
                 const float l10 = c10 * inv0;            // L[j+1][j]
-                const float u10 = -l10 * inv0;           // column j+1 after step j: cB[k] + u10 * cA[k]
+                const float u10 = -l10 * inv0;           // column j+1 after step j: B[k] + u10 * A[k]
                 float d1 = fmaf(u10, c10, b11);          // = A[j+1][j+1] - L[j+1][j]^2
                 if (!(d1 > pivot_floor)) {
                     d1 = pivot_floor > 0.0f ? pivot_floor : 1.0e-30f;
@@ -353,22 +354,23 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
                 asm volatile("" : "+v"(inv1));
                 pinv[j] = inv0;
                 pinv[j + 1] = inv1;
-                const float lij0 = a[j] * inv0;              // L[row][j]
+                const float aj0 = h ? other : b[p];          // this row's entries of columns j and j+1 (before step j)
+                const float aj1p = h ? b[p] : other;
+                const float lij0 = aj0 * inv0;               // L[row][j]
                 const float t0 = -lij0 * inv0;
-                a[j] = (leader && i == j) ? d0 * inv0 : lij0;
-                const float aj1 = fmaf(t0, c10, a[j + 1]);   // own entry of column j+1 after step j
+                const float aj1 = fmaf(t0, c10, aj1p);       // entry of column j+1 after step j
                 const float lij1 = aj1 * inv1;               // L[row][j+1]
                 const float t1 = -lij1 * inv1;
-                a[j + 1] = (leader && i == j + 1) ? d1 * inv1 : lij1;
+                b[p] = h ? ((leader && i == j + 1) ? d1 * inv1 : lij1) : ((leader && i == j) ? d0 * inv0 : lij0);
 #pragma unroll
-                for (int k = j + 2; k < 32; ++k) {
-                    const float c1 = fmaf(u10, ck0[k], ck1[k]);
-                    a[k] = fmaf(t1, c1, fmaf(t0, ck0[k], a[k]));
+                for (int m = p + 1; m < 16; ++m) {
+                    const float c1 = fmaf(u10, ck0[m], ck1[m]);
+                    b[m] = fmaf(t1, c1, fmaf(t0, ck0[m], b[m]));
                 }
             }
-            if (lane < 32) {
+            {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) Bw[i * LS + k] = (!leader || k <= i) ? a[k] : 0.0f;
+                for (int m = 0; m < 16; ++m) Bw[i * LS + 2 * m + h] = (!leader || 2 * m + h <= i) ? b[m] : 0.0f;
             }
         }
         LEAF_STAMP(1 + 2 * jb);
