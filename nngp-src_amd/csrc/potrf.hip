@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
                                                              float pivot_floor) {
     __shared__ float Lb[10 * BLK];
     __shared__ float Xb[10 * BLK];
-    __shared__ float Tb[3 * BLK];   // scratch of the inverse assembly (one block per active wave)
+    __shared__ float Tb[6 * BLK];   // scratch of the inverse assembly
     __shared__ float ring[16 * 64];  // line j/2: columns j and j+1 of the current diagonal sub-block before elimination step j (layout: see rd)
     __shared__ int step_flag;        // column pairs published so far: 16 jb + j/2 + 1
     const int tid = threadIdx.x, lane = tid & 63;
@@ -392,20 +392,31 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
     }
 
     // ---- the four diagonal inverses, one per wave: lane c owns column c of X = L^-1 ----
+    // Column-oriented forward substitution: once x[k] is known every later row's sum takes its term, s[r] += L[r][k] x[k] --
+    // independent FMAs (the row-oriented form is a dependent chain per row and ran 7.7k-12k cycles depending on how hipcc
+    // scheduled its LDS reads); the dependent chain is one FMA + one multiply per k.
     {
         const float* Djj = Lb + blk(wave, wave) * BLK;
         float* Xjj = Xb + blk(wave, wave) * BLK;
-        float x[32];
+        float x[32], sacc[32], lcol[3][32];  // lcol: columns k, k+1, k+2 of L (requested two steps ahead of their use:
+                                             // left alone, hipcc reads each column right before its FMAs and waits)
 #pragma unroll
-        for (int ii = 0; ii < 32; ++ii) {
-            float s0 = 0.0f, s1 = 0.0f;  // two chains: the sum is latency-, not throughput-bound
+        for (int r = 0; r < 32; ++r) sacc[r] = 0.0f;
 #pragma unroll
-            for (int k = 0; k + 1 < ii; k += 2) {
-                s0 = fmaf(Djj[ii * LS + k], x[k], s0);  // broadcast LDS reads
-                s1 = fmaf(Djj[ii * LS + k + 1], x[k + 1], s1);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = c + 1; r < 32; ++r) lcol[c][r] = Djj[r * LS + c];  // broadcast LDS reads
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k + 2 < 32) {
+#pragma unroll
+                for (int r = k + 3; r < 32; ++r) lcol[(k + 2) % 3][r] = Djj[r * LS + k + 2];
             }
-            if (ii & 1) s0 = fmaf(Djj[ii * LS + ii - 1], x[ii - 1], s0);
-            x[ii] = (((i == ii) ? 1.0f : 0.0f) - (s0 + s1)) * pinv[ii];
+            __builtin_amdgcn_sched_barrier(0);
+            x[k] = (((i == k) ? 1.0f : 0.0f) - sacc[k]) * pinv[k];
+#pragma unroll
+            for (int r = k + 1; r < 32; ++r) sacc[r] = fmaf(lcol[k % 3][r], x[k], sacc[r]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (lane < 32) {
 #pragma unroll
@@ -415,22 +426,49 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
     LEAF_STAMP(9);
     __syncthreads();
 
-    // ---- assemble the 128x128 inverse: X[ib][jb] = -Dinv_ii * sum_{k=jb}^{ib-1} L[ib][k] X[k][jb] ----
-#pragma unroll 1
-    for (int dist = 1; dist < 4; ++dist) {
-        const int ib = dist + wave, jb = wave;  // wave w owns block (dist + w, w)
-        const bool active = ib < 4;
-        float* scratch = Tb + (wave < 3 ? wave : 0) * BLK;
-        if (active) {
-            f32x16 t = zero16();
-            for (int k = jb; k < ib; ++k)
-                t = blk_mma<true>(Lb + blk(ib, k) * BLK, Xb + blk(k, jb) * BLK, t, 1.0f, lane);
-            blk_store(scratch, t, lane);
+    // ---- assemble the 128x128 inverse.  With 64x64 halves, X = [[X_lo, 0], [-X_hi L_hl X_lo, X_hi]]: the off-diagonal 32x32
+    // blocks of X_lo and X_hi first (X10, X32), together with the terms of T = L_hl X_lo that need neither; then the rest
+    // of T; then X[2..3][0..1] = -X_hi T.  Six block products on the critical path and three barriers (the block-row
+    // substitution this replaces: nine and six).  A wave reads back only scratch it wrote itself inside a phase (the LDS
+    // executes one wave's operations in order). ----
+    {
+        auto L_ = [&](int ib, int jb) { return Lb + blk(ib, jb) * BLK; };
+        auto X_ = [&](int ib, int jb) { return Xb + blk(ib, jb) * BLK; };
+        float* T00 = Tb + 0 * BLK; float* T01 = Tb + 1 * BLK; float* T10 = Tb + 2 * BLK; float* T11 = Tb + 3 * BLK;
+        float* S0 = Tb + 4 * BLK;  float* S1 = Tb + 5 * BLK;
+        // phase 1
+        if (wave == 0) {
+            blk_store(S0, blk_mma<true>(L_(1, 0), X_(0, 0), zero16(), 1.0f, lane), lane);
+            blk_store(X_(1, 0), blk_mma<true>(X_(1, 1), S0, zero16(), -1.0f, lane), lane);
+        } else if (wave == 1) {
+            blk_store(S1, blk_mma<true>(L_(3, 2), X_(2, 2), zero16(), 1.0f, lane), lane);
+            blk_store(X_(3, 2), blk_mma<true>(X_(3, 3), S1, zero16(), -1.0f, lane), lane);
+        } else if (wave == 2) {
+            blk_store(T01, blk_mma<true>(L_(2, 1), X_(1, 1), zero16(), 1.0f, lane), lane);
+            blk_store(T00, blk_mma<true>(L_(2, 0), X_(0, 0), zero16(), 1.0f, lane), lane);  // + L21 X10 in phase 2
+        } else {
+            blk_store(T11, blk_mma<true>(L_(3, 1), X_(1, 1), zero16(), 1.0f, lane), lane);
+            blk_store(T10, blk_mma<true>(L_(3, 0), X_(0, 0), zero16(), 1.0f, lane), lane);  // + L31 X10 in phase 2
         }
         __syncthreads();
-        if (active) {
-            f32x16 xr = blk_mma<true>(Xb + blk(ib, ib) * BLK, scratch, zero16(), -1.0f, lane);
-            blk_store(Xb + blk(ib, jb) * BLK, xr, lane);
+        // phase 2
+        if (wave == 0) {
+            blk_store(T00, blk_mma<true>(L_(2, 1), X_(1, 0), blk_load(T00, lane), 1.0f, lane), lane);
+        } else if (wave == 1) {
+            blk_store(T10, blk_mma<true>(L_(3, 1), X_(1, 0), blk_load(T10, lane), 1.0f, lane), lane);
+        } else if (wave == 2) {
+            blk_store(X_(2, 1), blk_mma<true>(X_(2, 2), T01, zero16(), -1.0f, lane), lane);
+        } else {
+            f32x16 q = blk_mma<true>(X_(3, 2), T01, zero16(), -1.0f, lane);
+            blk_store(X_(3, 1), blk_mma<true>(X_(3, 3), T11, q, -1.0f, lane), lane);
+        }
+        __syncthreads();
+        // phase 3
+        if (wave == 0) {
+            blk_store(X_(2, 0), blk_mma<true>(X_(2, 2), T00, zero16(), -1.0f, lane), lane);
+        } else if (wave == 1) {
+            f32x16 q = blk_mma<true>(X_(3, 2), T00, zero16(), -1.0f, lane);
+            blk_store(X_(3, 0), blk_mma<true>(X_(3, 3), T10, q, -1.0f, lane), lane);
         }
         __syncthreads();
     }
