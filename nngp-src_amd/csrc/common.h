@@ -28,7 +28,7 @@ void set_error(const char* fmt, ...);
 //      Cholesky on the float32 MFMA; 20 + c = float32 lead of 128 c columns in the first trailing update (default 256)
 //   4  compute units the persistent split-float16 grid leaves free (default 32 in the Cholesky); panel CUs of the CU-mask
 //      experiment
-//   5  2 = CU-masked streams; 9 = no split-K in the float64 GEMM; 10 + v = tile-block shape of the split-float16 GEMM
+//   5  2 = CU-masked streams; 9 = no split-K in the float64 GEMM; 8 = plain blockIdx tile order in the float64 GEMM; 10 + v = tile-block shape of the split-float16 GEMM
 //   6  >= 128: block size of the inverted diagonal blocks (default 1024); 1 = fixed covariance sweeps only and no retry
 //      of a broken-down factorisation; 2..30 = e: row-flag threshold 10^-e of the adaptive covariance
 //   7  1 = 128-wide recursion in the posterior solves; any non-zero value = float32 solve path; 3 = CG solve in stream

@@ -27,14 +27,22 @@ __device__ __forceinline__ int lds_off64(int row, int ch) { return row * 128 + (
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, const double* Cin, int64_t ldcin,
                                                         const double* A, int64_t lda, const double* B, int64_t ldb,
                                                         int tiles_m, int nk, double alpha, double beta, int kmode,
-                                                        int tiles_n, int ksplit, double* part, int64_t part_stride) {
+                                                        int tiles_n, int ksplit, double* part, int64_t part_stride, int xcd_order) {
     __shared__ __attribute__((aligned(16))) double smem[2 * DSTAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // row tile is the fast index: the workgroups that share one 128-row panel of B (the big symmetric kernel matrix)
-    // are dispatched together, so the panel is fetched from HBM once and served from L2 / Infinity Cache after that
-    const int tile = blockIdx.x % (tiles_m * tiles_n), kp = blockIdx.x / (tiles_m * tiles_n);
+    // Row tile is the fast index: the workgroups that share one 128-row panel of B (the big symmetric kernel matrix) are
+    // neighbours in tile order.  Workgroup b runs on XCD b % 8, so XCD x takes a CONTIGUOUS range of that order: the
+    // panel's sharers sit in one XCD's L2 and the panel leaves HBM once (with plain blockIdx order its tiles_m sharers
+    // were dealt to tiles_m different XCDs and each fetched it: 118 GB per posterior instead of the matrix's 8.6).
+    int g_ = blockIdx.x;
+    if (xcd_order) {
+        const int total = tiles_m * tiles_n * (ksplit > 1 ? ksplit : 1);
+        const int q = total >> 3, r = total & 7, x = g_ & 7, slot = g_ >> 3;
+        g_ = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+    }
+    const int tile = g_ % (tiles_m * tiles_n), kp = g_ / (tiles_m * tiles_n);
     const int bi = tile % tiles_m;
     int bj = tile / tiles_m;
     // kmode (B square and symmetric, quadratic forms z^T B z from its lower triangle only): 1 = only the k blocks
@@ -187,7 +195,7 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
     }
     if (ksplit <= 1) {
         hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
-                           a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, 1, nullptr, 0);
+                           a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, 1, nullptr, 0, NNGP_KNOB(5) != 8);
         NNGP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -198,7 +206,7 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
         NNGP_HIP_CHECK(hipMemsetAsync(part, 0, sizeof(double) * part_stride * ksplit, s));
     hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn * ksplit)), dim3(256), 0, s, c, ldc, cin ? cin : c,
                        ldcin ? ldcin : ldc, a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, ksplit, part,
-                       part_stride);
+                       part_stride, NNGP_KNOB(5) != 8);
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, s, c, ldc, cin ? cin : c,
                        ldcin ? ldcin : ldc, part, part_stride, ksplit, n, alpha, beta);
     NNGP_HIP_CHECK(hipGetLastError());
