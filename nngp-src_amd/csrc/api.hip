@@ -328,6 +328,13 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     return trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s);
 }
 
+// NTK covariance: the error of Z enters in first order (no cancellation as in the NNGP form), so what the sweeps leave is
+// what the variance gets, ~ rho^(sweeps + 1) with rho the contraction of the float32 factor as a solver.  Measured at
+// N = 16384, d = 256, join-block encoding, 4 CG iterations in the alpha solve (scripts/ntk_var_study.py, worst relative
+// error over 1024 queries against 4 sweeps / ms per predict): 1 sweep 2.7e-5 / 24.8, 2 sweeps 3.6e-8 / 36.8, 3 sweeps
+// 2.0e-8 / 49.0.  Levels <= 2: two sweeps; above: that many.
+static int ntk_sweeps(const nngp_model* m) { return m->var_refine < 2 ? 2 : m->var_refine; }
+
 // z64 <- rows of `rhs` [mp, np] times (K + reg I)^-1: float32 solves corrected by `sweeps` float64 residual sweeps.
 // final_residual: also leave r64 = rhs - z64 (K + reg I) for the returned z64 (one more float64 product).
 int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps, bool final_residual, hipStream_t s) {
@@ -1159,7 +1166,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(build_cross(m, xt, qt, mt, mp, true, m->ktd_aux, s));
         ktd_n = m->ktd_aux;
     }
-    NNGP_TRY(refined_solve_rows(m, ktd, mp, m->var_refine < 2 ? 2 : m->var_refine, false, s));  // no error cancellation: >= 2 sweeps
+    NNGP_TRY(refined_solve_rows(m, ktd, mp, ntk_sweeps(m), false, s));
     ntk_cross = ktd_n;
     z_valid = true;
     if (full) NNGP_TRY(build_ktt());
@@ -1177,7 +1184,10 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         // Iterations of the alpha solve against the variance error of the fixed sweeps, 72 random fits of
         // tests/test_gpu_parity.py (N <= 5200): <= 5: <= 1e-7, 6: <= 1e-5, 7: <= 5e-5, >= 9: up to 8e-2; the bench sizes
         // need 5 (N = 32768) and 6 (N = 65536).  NTK covariance has no second-order formula: stricter.
-        bool weak = m->iters >= (is_ntk ? 4 : 8) || m->reg_fac > m->reg;
+        // (NTK: two sweeps leave ~rho^3 where the NNGP formula leaves ~rho^4: 6 iterations ~ 2e-4, 5 ~ 6e-6, 4 ~ 4e-8 -- the
+        // threshold was 4 until round 2, which sent the N = 16384 bench config (4 iterations, 3.6e-8 after the sweeps) through
+        // three continuation steps, 78 ms per predict instead of 37)
+        bool weak = m->iters >= (is_ntk ? 6 : 8) || m->reg_fac > m->reg;
         // the row flag is the backstop for fits whose alpha solve says nothing (it converged in < 3 iterations, e.g.
         // y = 0); otherwise the iteration count decides and the call stays asynchronous
         if (!weak && check_kind != 3 && m->iters < 3) {

@@ -6,6 +6,7 @@ R=$(pwd)
 mkdir -p gpurun_out/r2
 O=gpurun_out/r2
 export TMPDIR=/tmp
+if [ "${PART:-A}" = "A" ]; then
 NNGP_FULL_ORACLE=${FULL:-0} timeout -k 10 1100 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout=900 > $O/pytest_gpu.log 2>&1
 echo "pytest exit=$?"; grep -a "passed\|failed\|^FAILED\|^ERROR" $O/pytest_gpu.log | cut -c1-300 | tail -6
 grep -a "CONFIG_CHECK" $O/pytest_gpu.log > $O/config_checks.txt
@@ -16,6 +17,8 @@ timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench_cfg3.json 2> 
 for C in cfg1 cfg2 cfg3 cfg4 cfg5; do python -c "
 import json
 d=json.loads(open('$O/bench_$C.json').read().strip().splitlines()[-1]); print('$C', d['ms_per_step'], d['stages_ms'], d['roofline']['frac'], d['roofline_posterior']['frac'], d['roofline_k1']['frac'])"; done
+fi
+if [ "${PART:-A}" = "B" ]; then
 # rocprofv3 kernel stats + timeline of the same bench command
 cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o cfg3 -- python3 $R/bench.py --config cfg3 --steps 3 --warmup 1 --no-cpu-baseline > $R/$O/prof.log 2>&1; echo "rocprof exit=$?"; cd $R
 T=$(find $O/prof -name "*kernel_trace.csv" | head -1); python3 scripts/trace_dump.py $T $O/timeline_cfg3.csv; cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/cfg3_kernel_stats.csv; rm -rf $O/prof
@@ -42,4 +45,5 @@ ab() {
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('debug=$1 $2', d['ms_per_step'], d['stages_ms']['cholesky'], d['fit_info']['cg_iters'])"
 }
-for r in 8 16 24 32 48; do ab "4=$r" cfg3; done
+for r in 24 32 48; do ab "4=$r" cfg3; done
+fi
