@@ -254,6 +254,9 @@ def main():
         e6 = ev()
         if stages is not None:
             torch.cuda.synchronize()
+            if ktimer["on"]:  # HIP events the library put around every trailing-update launch of this step's factorisation
+                nl, tms, tfl = model.update_timer_read()
+                ktimer["launches"] += nl; ktimer["ms"] += tms; ktimer["flops"] += tfl
             for k, (a, b) in {"set_train": (e0, e1), "kernel_build": (e1, e2), "allgather": (e2, e3),
                               "cholesky": (e3, e4), "alpha_solve": (e4, e5), "posterior": (e5, e6)}.items():
                 stages.setdefault(k, []).append(a.elapsed_time(b))
@@ -271,6 +274,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
 
+    # live timing of the dominant kernel (k_gemm_nt_h3, the Cholesky's split-float16 trailing update) for `roofline`
+    ktimer = {"on": False, "launches": 0, "ms": 0.0, "flops": 0.0}
+    if not (shard and dist_chol):
+        try:
+            model.update_timer(True)
+            ktimer["on"] = True
+        except _lib.NngpError:
+            pass
     for _ in range(args.warmup):
         step()
     barrier()
@@ -318,10 +329,14 @@ def main():
             (rep,) = max_over_ranks([(time.perf_counter() - tr) / 2 * 1e3])
             shard_report["replicate_layout_ms_per_step"] = round(rep, 3)
 
-    traffic, traffic_src = None, None
+    traffic, traffic_src, k_traffic = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg_name)
     if os.path.exists(tpath):  # HBM bytes of the Cholesky kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
-        traffic = json.load(open(tpath)).get("cholesky_bytes")
+        _pm = json.load(open(tpath))
+        traffic = _pm.get("cholesky_bytes")
+        _k = _pm.get("kernels", {}).get("k_gemm_nt_h3<true>")
+        if _k and _k.get("calls"):
+            k_traffic = (_k["fetch_bytes"] + _k["write_bytes"]) / _k["calls"]
         traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
     if rank == 0:
         fl = flop_model(n, d, m, n_relu)
@@ -345,10 +360,11 @@ def main():
                        "precision": "float64 kernel build + CG residual; float32 Cholesky (preconditioner) whose trailing updates run "
                                     "as split-float16 MFMA products (hi+lo, 3 per term, float32 accumulate); float64 means; variances: "
                                     "float32 solves + one float64 residual product (level 1)"},
+            "roofline": None,  # filled in below: the dominant kernel when the library timed it, else the stage
             # Cholesky stage = the dominant cost.  `achieved` = algorithmic F_C / stage time.  Its matrix work runs on the
             # float16 pipe at 3 products per float32-grade term, so the hardware peak for it is PEAK_F16 / 3; the
             # fraction of the float32-MFMA roofline the north star names is reported beside it (it can exceed 1).
-            "roofline": {"bound": "mfma", "achieved": round(chol_tflops, 3), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1),
+            "roofline_cholesky_stage": {"bound": "mfma", "achieved": round(chol_tflops, 3), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1),
                          "unit": "TFLOP/s", "frac": round(chol_tflops / (PEAK_F16_MFMA_TFLOPS / 3), 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel": "Cholesky stage (k_gemm_nt_h3 trailing updates + k_gemm_nt_f32 panel GEMMs + k_potrf_leaf), "
@@ -378,6 +394,30 @@ def main():
             "fit_info": {"cg_iters": info["refine_iters"], "rel_residual": info["rel_residual"],
                          "clamped_pivots": info["clamped_pivots"], "reg": info["reg"], "alpha_l2": alpha_l2},
         }
+        if ktimer["on"] and ktimer["launches"] > 0 and ktimer["ms"] > 0.0:
+            # `roofline` = the DOMINANT KERNEL, measured live: HIP events around every k_gemm_nt_h3<lower> launch, on the stream
+            # it is launched on (nngp_model_update_timer), summed over the timed steps.  achieved = algorithmic flops of the
+            # launches (2 x updated entries x panel width: float32-grade work) / their summed duration; the kernel executes
+            # three float16 MFMA products per term, so the pipe's peak for this work is PEAK_F16 / 3.
+            k_tflops = ktimer["flops"] / (ktimer["ms"] * 1e-3) / 1e12
+            per_step = ktimer["launches"] / args.steps
+            result["roofline"] = {
+                "bound": "mfma", "achieved": round(k_tflops, 3), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s",
+                "frac": round(k_tflops / (PEAK_F16_MFMA_TFLOPS / 3), 4),
+                "traffic": k_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_h3<true>, per launch") if k_traffic else None,
+                "kernel": "k_gemm_nt_h3<LOWER=true> (split-float16 trailing update of the blocked Cholesky)",
+                "launches_per_step": round(per_step, 2), "avg_launch_ms": round(ktimer["ms"] / ktimer["launches"], 4),
+                "ms_per_step_in_kernel": round(ktimer["ms"] / args.steps, 3),
+                "algorithmic_flops_per_launch": round(ktimer["flops"] / ktimer["launches"], 1),
+                "algorithmic_bytes_per_launch": round((8.0 * ktimer["flops"] / ktimer["launches"] / (2.0 * 1024)) , 1),
+                "bytes_note": "C read + written once per launch (8 B per updated float32 entry, entries = flops / (2 x 1024)); the "
+                              "operand panels add 4 B x rows x 1024 once",
+                "executed_f16_mfma_tflops": round(3 * k_tflops, 1),
+                "peak_note": "dense f16 MFMA peak %.1f TF/s / 3 products per float32-grade term" % PEAK_F16_MFMA_TFLOPS,
+                "timer": "HIP events on the update stream around each launch (library: nngp_model_update_timer), timed steps only",
+            }
+        else:
+            result["roofline"] = dict(result["roofline_cholesky_stage"])
         if shard_report is not None:
             result["shard"] = shard_report
         elif world > 1:

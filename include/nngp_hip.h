@@ -144,6 +144,14 @@ int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** d
  * can all-gather row blocks over RCCL between build_rows and factor. */
 int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld);
 int nngp_model_info(nngp_model* m, nngp_fit_info* info /* host */);
+/* Live timing of the path's dominant kernel, the split-float16 trailing update of the Cholesky (k_gemm_nt_h3, lower):
+ * with the timer on, nngp_model_factor brackets every such launch with a pair of HIP events on the stream it is launched
+ * on (bench.py's `roofline` object; no reference counterpart -- the reference prints wall-clock seconds, train.py:176,195).
+ * _read waits for the last factorisation and returns, for it: the launches, their summed duration and their algorithmic
+ * work, 2 * (updated entries on or below the diagonal) * (panel width) flops, float32-grade (the kernel executes three
+ * float16 MFMA products per term).  Any out pointer may be NULL. */
+int nngp_model_update_timer(nngp_model* m, int32_t enable);
+int nngp_model_update_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total);
 /* alpha = (K + reg I)^-1 Y, [n, ny] f64, copied to a device buffer. */
 int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
 

@@ -893,6 +893,30 @@ int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld) {
     return 0;
 }
 
+int nngp_model_update_timer(nngp_model* m, int32_t enable) {
+    NNGP_REQUIRE(m != nullptr, "update_timer: NULL model");
+    NNGP_REQUIRE(m->la != nullptr, "update_timer: this model has no look-ahead factorisation (too small)");
+    m->la->time_updates = enable != 0;
+    m->la->tu_count = 0;
+    return 0;
+}
+
+int nngp_model_update_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total) {
+    NNGP_REQUIRE(m != nullptr && m->la != nullptr, "update_timer_read: no timer on this model");
+    double ms = 0.0, fl = 0.0;
+    for (int t = 0; t < m->la->tu_count; ++t) {
+        NNGP_HIP_CHECK(hipEventSynchronize(m->la->tu1[t]));
+        float e = 0.0f;
+        NNGP_HIP_CHECK(hipEventElapsedTime(&e, m->la->tu0[t], m->la->tu1[t]));
+        ms += e;
+        fl += m->la->tu_flops[t];
+    }
+    if (launches) *launches = m->la->tu_count;
+    if (ms_total) *ms_total = ms;
+    if (flops_total) *flops_total = fl;
+    return 0;
+}
+
 int nngp_model_info(nngp_model* m, nngp_fit_info* info) {
     NNGP_REQUIRE(m != nullptr && info != nullptr, "model_info: NULL argument");
     NNGP_TRY(run_pending_solve(m, nullptr, false));

@@ -157,6 +157,11 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     bool masked = false;  // streams own disjoint CU sets (hipExtStreamCreateWithCUMask)
     hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
     hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};
+    // live timing of the split-float16 trailing updates (nngp_model_update_timer): event pairs around each launch
+    bool time_updates = false;
+    hipEvent_t tu0[kMaxSteps] = {}, tu1[kMaxSteps] = {};
+    int tu_count = 0;              // launches of the last factorisation
+    double tu_flops[kMaxSteps] = {};
 };
 int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);

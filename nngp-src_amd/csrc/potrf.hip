@@ -636,6 +636,10 @@ void lookahead_destroy(LookAhead* la) {
     (void)hipStreamDestroy(la->update);
     (void)hipEventDestroy(la->ev_in); (void)hipEventDestroy(la->ev_panel_done); (void)hipEventDestroy(la->ev_update_done);
     for (int i = 0; i < LookAhead::kMaxSteps; ++i) { (void)hipEventDestroy(la->ev_panel[i]); (void)hipEventDestroy(la->ev_col[i]); }
+    for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
+        if (la->tu0[i]) (void)hipEventDestroy(la->tu0[i]);
+        if (la->tu1[i]) (void)hipEventDestroy(la->tu1[i]);
+    }
     delete la;
 }
 
@@ -657,6 +661,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     // 58.9 ms, and 58.1 vs 57.9 ms with CUs reserved for the panel stream -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || NNGP_KNOB(2) == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
+    la->tu_count = 0;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_in, 0));
@@ -757,10 +762,23 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // solves of the posterior read it again)
                 char* planes = pk_rows;
                 if (rc == 0 && !panel_split_done) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
+                const bool timed = la->time_updates && rc == 0 && la->tu_count < LookAhead::kMaxSteps;
+                if (timed) {  // events are created on first use (timing stream: the one the kernel is launched on)
+                    const int t = la->tu_count;
+                    if (la->tu0[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu0[t]));
+                    if (la->tu1[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu1[t]));
+                    NNGP_HIP_CHECK(hipEventRecord(la->tu0[t], la->update));
+                }
                 if (rc == 0)  // columns [lead, nbk) of the panel (K blocks are walked from the high end down)
                     rc = launch_gemm_nt_h3(c + nb2 * ld, ld, planes + nb2 * ldp + lead * 4, planes + lead * 4, ldp, m - nb2, m,
                                            nbk - lead, -1.0f / (sw->scale * sw->scale), 1.0f, true, nb2, sw->counters, reserve,
                                            la->update);
+                if (timed) {
+                    const int t = la->tu_count++;
+                    NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
+                    // entries on or below the diagonal in rows [nb2, m) of the m x m trailing matrix
+                    la->tu_flops[t] = 2.0 * (0.5 * ((double)m * (m + 1) - (double)nb2 * (nb2 + 1))) * (double)(nbk - lead);
+                }
                 if (rc == 0 && lead > 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, lead, -1.0f, 1.0f, false, la->update);
                 if (rc == 0 && lead > 0)

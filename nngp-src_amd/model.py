@@ -202,6 +202,18 @@ class GPModel:
         self._check(self.lib.nngp_model_info(self.handle, ctypes.byref(fi)))
         return {k: getattr(fi, k) for k, _ in fi._fields_}
 
+    def update_timer(self, enable=True):
+        """Live HIP-event timing of the dominant kernel (the Cholesky's split-float16 trailing update); see update_timer_read."""
+        self._check(self.lib.nngp_model_update_timer(self.handle, 1 if enable else 0))
+
+    def update_timer_read(self):
+        """(launches, total ms, algorithmic flops) of the trailing updates of the last factorisation (waits for it)."""
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0.0)
+        fl = ctypes.c_double(0.0)
+        self._check(self.lib.nngp_model_update_timer_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        return int(n.value), float(ms.value), float(fl.value)
+
     def alpha(self):
         import torch
         out = torch.empty((self.n, self.ny), dtype=torch.float64, device=self.device)

@@ -313,3 +313,34 @@ def test_checkpoint_save_and_resume(tmp_path):
     np.savez(str(tmp_path / "bad.npz"), **z)
     with pytest.raises(Exception):
         GPModel.load(str(tmp_path / "bad.npz"))
+
+
+def test_update_timer_reports_the_trailing_update_launches():
+    """bench.py's `roofline` is measured live: nngp_model_update_timer puts HIP events around every split-float16 trailing
+    update of the factorisation.  N = 5120 = 5 block columns: columns 0..2 have a trailing matrix beyond the next diagonal
+    block (m = 4096, 3072, 2048 > 1024), so three launches; their algorithmic work is 2 x (entries on or below the diagonal
+    in rows >= 1024 of the m x m trailing matrix) x (panel width; the first panel keeps 256 lead columns on the float32 MFMA).
+    The numbers must not change the fit."""
+    n, d = 5120, 16
+    x, y = synth.synthetic_queries(n, d, seed=21)
+    model = GPModel(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3)
+    model.fit(x, y)
+    a0 = model.alpha().cpu().numpy()
+    model.update_timer(True)
+    model.fit(x, y)
+    launches, ms, flops = model.update_timer_read()
+    assert launches == 3 and ms > 0.0
+    want = 0.0
+    for k, m in enumerate((4096, 3072, 2048)):
+        width = 1024 - (256 if k == 0 else 0)
+        want += 2.0 * 0.5 * (m * (m + 1) - 1024 * 1025) * width
+    assert flops == pytest.approx(want, rel=1e-12)
+    np.testing.assert_array_equal(model.alpha().cpu().numpy(), a0)
+    model.update_timer(False)
+    model.fit(x, y)
+    assert model.update_timer_read()[0] == 0
+    # a model too small for the look-ahead factorisation still answers (no launches)
+    small = GPModel(512, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x[:512], y[:512])
+    small.update_timer(True)
+    small.fit(x[:512], y[:512])
+    assert small.update_timer_read()[0] == 0
