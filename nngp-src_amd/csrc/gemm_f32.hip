@@ -170,8 +170,8 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
                                int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int batch,
                                int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s) {
     if (m <= 0 || n <= 0 || batch <= 0) return 0;
-    NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % 128 == 0 && k > 0,
-                 "gemm_nt_f32: dims must be multiples of 128 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n,
+    NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % BK == 0 && k > 0,
+                 "gemm_nt_f32: m, n must be multiples of 128 and k of 32 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n,
                  (long long)k);
     NNGP_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
                      ((uintptr_t)c & 3) == 0 && stride_a % 4 == 0 && stride_b % 4 == 0,

@@ -746,11 +746,14 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
             // trailing update costs two CG iterations and 40x in the refined variances, so the first `lead` columns
             // of block column 0 go through the float32-MFMA kernels and the rest through the float16 pipe.  Measured at
             // N = 32768 (Cholesky ms / CG iterations / level-2 variance error): lead 0: 59.8 / 7 / 1.6e-5, 128: 61.0 / 6 /
-            // 4.1e-7, 256: 61.9 / 5 / 4.0e-7, 512: 63.6 / 6, whole column: 63.6 / 5 / 4.0e-7.
-            // (debug key 3 = 10 + n: n whole block columns on float32; 20 + c: lead = 128 c)
+            // 4.1e-7, 256: 61.9 / 5 / 4.0e-7, 512: 63.6 / 6, whole column: 63.6 / 5 / 4.0e-7.  Round 2 (scripts/lead_study.py;
+            // level-1 variance against level 3): 0: 47.1 / 7 / 7.5e-5, 32: 47.6 / 6 / 1.16e-6, 64: 47.8 / 5 / 1.13e-6, 128: 48.0 /
+            // 5 / 1.13e-6, 256: 48.8 / 6 / 1.17e-6 -- the bias sits in the first few (dominant, one-signed) columns: 64 it is.
+            // (debug key 3 = 10 + n: n whole block columns on float32; 20 + c: lead = 128 c; 31 / 32: lead = 32 / 64)
             const bool f32_first = !h3 || (NNGP_KNOB(3) >= 10 && NNGP_KNOB(3) < 20 && k < NNGP_KNOB(3) - 10);
             int64_t lead = 0;
-            if (h3 && !f32_first && k == 0) lead = (NNGP_KNOB(3) >= 20 && NNGP_KNOB(3) < 28) ? 128 * (int64_t)(NNGP_KNOB(3) - 20) : 256;
+            if (h3 && !f32_first && k == 0) lead = (NNGP_KNOB(3) >= 20 && NNGP_KNOB(3) < 28) ? 128 * (int64_t)(NNGP_KNOB(3) - 20) :
+                                                  (NNGP_KNOB(3) == 31 || NNGP_KNOB(3) == 32) ? 32 * (int64_t)(NNGP_KNOB(3) - 30) : 64;
             if (lead > nbk - 128) lead = 0;
             if (!f32_first) {
                 // the persistent GEMM grid leaves `reserve` compute units to the panel stream, whose small kernels
@@ -837,7 +840,7 @@ int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, in
             NNGP_TRY(launch_split_rows(a + (po + pw) * ld + po, ld, n - po - pw, pw, sw->scale, col + (po + pw) * ldp, ldp, s));
             sw->split_panel = po;
         }
-        const int64_t lead = (po == 0 && pw > 256) ? 256 : 0;
+        const int64_t lead = (po == 0 && pw > 256) ? 64 : 0;  // as in potrf_lookahead_f32
         NNGP_TRY(launch_gemm_nt_h3(c, ld, col + o * ldp + lead * 4, col + o * ldp + lead * 4, ldp, n - o, w, pw - lead,
                                    -1.0f / (sw->scale * sw->scale), 1.0f, true, 0, sw->counters, 0, s));
         if (lead > 0) {

@@ -319,7 +319,7 @@ def test_update_timer_reports_the_trailing_update_launches():
     """bench.py's `roofline` is measured live: nngp_model_update_timer puts HIP events around every split-float16 trailing
     update of the factorisation.  N = 5120 = 5 block columns: columns 0..2 have a trailing matrix beyond the next diagonal
     block (m = 4096, 3072, 2048 > 1024), so three launches; their algorithmic work is 2 x (entries on or below the diagonal
-    in rows >= 1024 of the m x m trailing matrix) x (panel width; the first panel keeps 256 lead columns on the float32 MFMA).
+    in rows >= 1024 of the m x m trailing matrix) x (panel width; the first panel keeps 64 lead columns on the float32 MFMA).
     The numbers must not change the fit."""
     n, d = 5120, 16
     x, y = synth.synthetic_queries(n, d, seed=21)
@@ -332,7 +332,7 @@ def test_update_timer_reports_the_trailing_update_launches():
     assert launches == 3 and ms > 0.0
     want = 0.0
     for k, m in enumerate((4096, 3072, 2048)):
-        width = 1024 - (256 if k == 0 else 0)
+        width = 1024 - (64 if k == 0 else 0)
         want += 2.0 * 0.5 * (m * (m + 1) - 1024 * 1025) * width
     assert flops == pytest.approx(want, rel=1e-12)
     np.testing.assert_array_equal(model.alpha().cpu().numpy(), a0)
