@@ -774,6 +774,9 @@ constexpr int kSolveAhead = 6;  // run-ahead experiment (nngp_model_solve): the 
 // Stopping tolerance of the early-stopped solve.  Measured at N = 32768 (ms per step / error of the corrected mean): 1e-6:
 // 150.0 / 8e-11, 1e-4: 147.5 / 4e-9, 1e-2: 145.9 / 2e-7.  1e-6 it is: the iteration count extrapolated from a solve stopped
 // at 1e-4 underestimates slowly converging fits (two of the sweep's 72 cases then missed the adaptive covariance).
+// (Round 2, level-1 variance: 1e-4 saves 2.2 of 113 ms; a two-staged stop -- 1e-4 only if reached within three iterations --
+// kept the adaptive covariance right, but the corrected means at N = 8192 / 32768 then sit 1.3e-6 / 4.8e-6 (elementwise)
+// from the oracle instead of 3e-9: not taken.)
 constexpr double kPartialTol = 1e-6;
 
 // iterations the solve needs (or would need) to reach pend_tol, from the rate it converged at

@@ -1,7 +1,7 @@
 #!/bin/bash
 # whole GPU suite, then the bench on the configs given (default cfg3)
 export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/full_pytest.log 2>&1 || { tail -40 gpurun_out/full_pytest.log; exit 1; }
+timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/full_pytest.log 2>&1 || { tail -40 gpurun_out/full_pytest.log; exit 1; }
 tail -3 gpurun_out/full_pytest.log
 for C in ${CFGS:-cfg3}; do
   python bench.py --config $C --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
