@@ -52,10 +52,11 @@ def flop_model(n, d, m, n_relu):
 
 
 def cpu_baseline(n_bench, d, m, n_relu, gpu_ms):
-    """The C float64/OpenMP oracle ("port") on bounded samples of the same workload, host cores of this box:
-    N in {4096, 8192, 16384}, least-squares fit t = a N^2 + b N^3, labelled extrapolation to N_bench."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import c_oracle
+    """The host build of the same C ABI (oracle/libnngp_cpu.so: include/nngp_hip.h on the float64 C/OpenMP oracle, "port") on
+    bounded samples of the same workload, host cores of this box: N in {4096, 8192, 16384}, least-squares
+    fit t = a N^2 + b N^3, labelled extrapolation to N_bench."""
+    sys.path.insert(0, ROOT)
+    from oracle import c_abi
     from nngp_src_amd import synth
     lapack = None
     try:  # second opinion on the dominant stage, timed BEFORE the OpenMP oracle spins up its threads:
@@ -71,31 +72,38 @@ def cpu_baseline(n_bench, d, m, n_relu, gpu_ms):
         del a, g
     except Exception as e:  # pragma: no cover
         lapack = {"error": str(e)}
-    c_oracle.set_threads(min(16, os.cpu_count() or 1))  # the GPU box gives one GPU a 16-core CPU share
+    c_abi.set_threads(min(16, os.cpu_count() or 1))  # the GPU box gives one GPU a 16-core CPU share
     w, b = [1.0] * (n_relu + 1), [0.0] * (n_relu + 1)
     sizes = [int(v) for v in os.environ.get("NNGP_CPU_SIZES", "4096,8192,16384").split(",")]
     mm = min(m, 256)
     xt, _ = synth.synthetic_queries(mm, d, seed=1)
-    c_oracle.kernel_build(xt, None, "nngp", w, b)  # warm the thread pool
+    c_abi.kernel_build(xt, None, "nngp", w, b)  # warm the thread pool
     samples = []
     for n in sizes:
         x, y = synth.synthetic_queries(n, d, seed=0)
+        model = c_abi.CpuModel(n, d, w, b, get="nngp", diag_reg=1e-3, m_cap=mm)
         t0 = time.perf_counter()
-        model = c_oracle.fit(x, y, w, b, get="nngp")
-        c_oracle.predict_nngp(model, xt, 1)
+        model.set_train(x, y)
+        model.build_rows(0, n)
+        t1 = time.perf_counter()
+        model.factor()
+        t2 = time.perf_counter()
+        model.solve()
+        model.predict(xt, "diag")
         dt = time.perf_counter() - t0
         fl = flop_model(n, d, mm, n_relu)
-        samples.append({"N": n, "M": mm, "sec": round(dt, 3), "build_sec": round(float(model["stage_sec"][0]), 3),
-                        "potrf_sec": round(float(model["stage_sec"][1]), 3), "gflops": round(fl["total"] / dt / 1e9, 2)})
+        samples.append({"N": n, "M": mm, "sec": round(dt, 3), "build_sec": round(t1 - t0, 3),
+                        "potrf_sec": round(t2 - t1, 3), "gflops": round(fl["total"] / dt / 1e9, 2)})
         del model, x, y
     ns = np.array([s["N"] for s in samples], dtype=np.float64)
     ts = np.array([s["sec"] for s in samples])
     coef, *_ = np.linalg.lstsq(np.stack([ns ** 2, ns ** 3], axis=1), ts, rcond=None)
     t_bench = float(coef[0] * n_bench ** 2 + coef[1] * n_bench ** 3)
     big = samples[-1]
-    out = {"value": big["gflops"], "unit": "GFLOP/s", "cores": c_oracle.num_threads(), "kind": "port",
-           "sample": "same step (kernel build + float64 Cholesky + alpha + posterior for M=%d) by the float64 C/OpenMP oracle at "
-                     "N = %s, d=%d, n_relu=%d; `value` is the largest sample" % (mm, sizes, d, n_relu),
+    out = {"value": big["gflops"], "unit": "GFLOP/s", "cores": c_abi.num_threads(), "kind": "port",
+           "sample": "same step (set_train + build_rows + factor + solve + predict(diag) for M=%d) through the host build of the same "
+                     "C ABI (oracle/libnngp_cpu.so: float64 C/OpenMP) at N = %s, d=%d, n_relu=%d; `value` is the largest sample"
+                     % (mm, sizes, d, n_relu),
            "samples": samples,
            "extrapolation": {"model": "t = a N^2 + b N^3 (least squares over the samples)", "a": float(coef[0]), "b": float(coef[1]),
                              "N": n_bench, "cpu_sec_extrapolated": round(t_bench, 2),

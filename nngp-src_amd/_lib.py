@@ -69,6 +69,14 @@ def load(knobs: bool = False):
     # up with two HSA runtimes and the second one reports "no ROCm-capable device" (seen on the GPU box).
     import torch  # noqa: F401
     lib = ctypes.CDLL(path)
+    bind_prototypes(lib, knobs)
+    _libs[knobs] = lib
+    return lib
+
+
+def bind_prototypes(lib, knobs: bool = False):
+    """Argument and result types of every entry point of include/nngp_hip.h on a loaded library.  Also applied by the test
+    infrastructure to its host build of the same ABI, so that both sit behind one interface."""
     vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
     archp = ctypes.POINTER(NngpArch)
     lib.nngp_version.restype = ctypes.c_int
@@ -117,10 +125,11 @@ def load(knobs: bool = False):
     lib.nngp_comm_library.restype = ctypes.c_char_p
     lib.nngp_allgather_rows.argtypes = [vp, i64, i64, i32, vp, vp]
     lib.nngp_bcast.argtypes = [vp, i64, i32, i32, vp, vp]
+    lib.nngp_model_update_timer.argtypes = [vp, i32]
+    lib.nngp_model_update_timer_read.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     for name in ABI_SYMBOLS:
         if name not in ("nngp_last_error", "nngp_model_factor_shift", "nngp_comm_library"):
             getattr(lib, name).restype = ctypes.c_int
-    _libs[knobs] = lib
     return lib
 
 

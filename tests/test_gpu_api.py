@@ -344,3 +344,34 @@ def test_update_timer_reports_the_trailing_update_launches():
     small.update_timer(True)
     small.fit(x[:512], y[:512])
     assert small.update_timer_read()[0] == 0
+
+
+@pytest.mark.parametrize("get", ["nngp", "ntk"])
+def test_hip_build_and_host_build_of_the_abi_agree(get):
+    """One interface, two builds: the call sequence create / set_train / build_rows / factor / solve / alpha / info / predict
+    through libnngp_hip.so (device pointers, mixed precision) and through the host build of the same header
+    (oracle/libnngp_cpu.so: host pointers, float64 -- the checker) gives the same numbers."""
+    from oracle import c_abi
+    n, d, m = 1100, 24, 70
+    x, y = synth.synthetic_queries(n, d, seed=31)
+    xt, _ = synth.synthetic_queries(m, d, seed=32)
+    w, b = [1.1, 1.0, 0.9], [0.05, 0.0, 0.1]
+    hip = GPModel(n, d, w, b, get=get, diag_reg=1e-3)
+    cpu = c_abi.CpuModel(n, d, w, b, get=get, diag_reg=1e-3)
+    for model in (hip, cpu):
+        model.set_train(x, y)
+        model.build_rows(0, n // 2)
+        model.build_rows(n // 2, n)
+        model.factor()
+        model.solve()
+    a_hip, a_cpu = hip.alpha().cpu().numpy(), cpu.alpha()
+    assert np.linalg.norm(a_hip - a_cpu) <= 1e-7 * np.linalg.norm(a_cpu)
+    i_hip, i_cpu = hip.info(), cpu.info()
+    assert i_hip["n"] == i_cpu["n"] == n and i_hip["reg"] == pytest.approx(i_cpu["reg"], rel=1e-8)
+    mean_h, var_h = hip.predict(xt, cov="diag")
+    mean_c, var_c = cpu.predict(xt, "diag")
+    assert np.linalg.norm(mean_h - mean_c) <= 1e-7 * np.linalg.norm(mean_c)
+    np.testing.assert_allclose(var_h, var_c, rtol=1e-4)
+    _, cov_h = hip.predict(xt, cov="full")
+    _, cov_c = cpu.predict(xt, "full")
+    np.testing.assert_allclose(cov_h, cov_c, rtol=1e-3, atol=1e-6 * np.abs(cov_c).max())
