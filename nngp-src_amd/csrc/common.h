@@ -204,11 +204,17 @@ int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_
 // in-place solves L x = b / L^T x = b on a float32 vector of length np
 int trsv_forward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, float* x, hipStream_t s);
 int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, float* b, float* x, hipStream_t s);
+// y = (A + diag_add I) x for a SYMMETRIC n x n float64 matrix stored in full, reading only its lower triangle (half the bytes
+// of launch_gemv_f64); part: [ceil(n/128)][np] workspace, np = ceil(n/128)*128.  Deterministic (fixed summation order).
+int launch_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, double* part,
+                    int64_t np, hipStream_t s);
 int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, const double* x, int64_t incx,
                     double* y, int64_t incy, double diag_add, hipStream_t s);
 struct PcgWork {
     double* r; double* z; double* p; double* q; double* xcol; double* bcol;
     float* f32a; float* f32b; float* f32c;
+    double* symv_part = nullptr;  // [np / 128][np]: per-tile partial results of the symmetric matrix-vector product
+    int64_t symv_np = 0;          // its np (0: not allocated -> plain GEMV)
     double* scal;       // device scalars [32]: 0..4 CG scalars, 6..7 trace / max of the diagonal, 8.. CG residual history
     double* host_scal;  // pinned host [32]
 };

@@ -85,6 +85,74 @@ __global__ __launch_bounds__(256) void k_transpose_blocks(const float* __restric
     for (int k = 0; k < 4; ++k) dst[base + (c0 + ty + 8 * k) * bs + r0 + tx] = tile[tx][ty + 8 * k];
 }
 
+// ---- float64 symmetric matrix-vector product from the lower triangle (the CG's A p: 8 N^2 / 2 bytes instead of 8 N^2) ----
+// One workgroup per 128 x 128 tile (I >= J) of the lower triangle: u = A_IJ x_J goes to part[J][rows of I] and, off the
+// diagonal, v = A_IJ^T x_I to part[I][rows of J] -- every (block, rows) slot of `part` is written by exactly one tile, and
+// k_symv_reduce sums a row's slots in a fixed order.  Wave w owns rows 32 w .. 32 w + 31 of the tile, lane l columns l and 64 + l.
+__global__ __launch_bounds__(256) void k_symv_tiles_f64(const double* __restrict__ A, int64_t lda, int64_t n,
+                                                        const double* __restrict__ x, double* __restrict__ part, int64_t np) {
+    __shared__ double xs[2][128];
+    __shared__ double us[128];
+    __shared__ double vs[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t p = blockIdx.x;
+    int64_t I = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > p) --I;
+    while ((I + 1) * (I + 2) / 2 <= p) ++I;
+    const int64_t J = p - I * (I + 1) / 2;
+    if (tid < 128) {
+        const int64_t ri = I * 128 + tid, rj = J * 128 + tid;
+        xs[0][tid] = ri < n ? x[ri] : 0.0;
+        xs[1][tid] = rj < n ? x[rj] : 0.0;
+    }
+    __syncthreads();
+    const int64_t c0 = J * 128 + lane, c1 = c0 + 64;
+    const bool ok0 = c0 < n, ok1 = c1 < n;
+    const double xj0 = xs[1][lane], xj1 = xs[1][64 + lane];
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll 1
+    for (int r8 = 0; r8 < 32; r8 += 8) {
+        double a0[8], a1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {  // eight rows' loads in flight
+            const int64_t r = I * 128 + wave * 32 + r8 + e;
+            const double* ar = A + r * lda;
+            a0[e] = (r < n && ok0) ? ar[c0] : 0.0;
+            a1[e] = (r < n && ok1) ? ar[c1] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double xi = xs[0][wave * 32 + r8 + e];
+            v0 = fma(a0[e], xi, v0);
+            v1 = fma(a1[e], xi, v1);
+            double sdot = fma(a0[e], xj0, a1[e] * xj1);
+            for (int off = 32; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off);
+            if (lane == 0) us[wave * 32 + r8 + e] = sdot;
+        }
+    }
+    vs[wave][lane] = v0;
+    vs[wave][64 + lane] = v1;
+    __syncthreads();
+    if (tid < 128) {
+        part[J * np + I * 128 + tid] = us[tid];
+        if (I != J) part[I * np + J * 128 + tid] = (vs[0][tid] + vs[1][tid]) + (vs[2][tid] + vs[3][tid]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_symv_reduce_f64(const double* __restrict__ part, int64_t nblk, int64_t np, int64_t n,
+                                                         const double* __restrict__ x, double diag_add, double* __restrict__ y) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t c = 0;
+    for (; c + 1 < nblk; c += 2) {
+        s0 += part[c * np + r];
+        s1 += part[(c + 1) * np + r];
+    }
+    if (c < nblk) s0 += part[c * np + r];
+    y[r] = fma(diag_add, x[r], s0 + s1);
+}
+
 // ---- float64 GEMV: y[i*incy] = sum_j A[i][j] x[j*incx] + diag_add * x[i*incx] ----
 __global__ __launch_bounds__(256) void k_gemv_f64(const double* __restrict__ A, int64_t lda, int64_t rows,
                                                   int64_t cols, const double* __restrict__ x, int64_t incx,
@@ -344,6 +412,17 @@ int trsv_backward_f32(const float* l, int64_t ld, const TriInv& ti, int64_t np, 
     return 0;
 }
 
+int launch_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, double* part,
+                    int64_t np, hipStream_t s) {
+    if (n <= 0) return 0;
+    NNGP_REQUIRE(part != nullptr && np % 128 == 0 && np >= n, "symv_f64: bad workspace");
+    const int64_t nblk = (n + 127) / 128;
+    hipLaunchKernelGGL(k_symv_tiles_f64, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, a, lda, n, x, part, np);
+    hipLaunchKernelGGL(k_symv_reduce_f64, dim3(blocks256(n)), dim3(256), 0, s, part, nblk, np, n, x, diag_add, y);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, const double* x, int64_t incx,
                     double* y, int64_t incy, double diag_add, hipStream_t s) {
     if (rows <= 0) return 0;
@@ -372,7 +451,10 @@ int pcg_iteration(const double* k64, int64_t ld, int64_t n, double reg, const fl
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.z, n, w.scal + 2);  // rz_new
     hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks256(n)), dim3(256), 0, s, w.p, w.z, n, w.scal, it == 0);
     hipLaunchKernelGGL(k_scal_shift, dim3(1), dim3(1), 0, s, w.scal);  // rz = rz_new
-    NNGP_TRY(launch_gemv_f64(k64, ld, n, n, w.p, 1, w.q, 1, reg, s));
+    if (w.symv_part != nullptr && w.symv_np >= np && NNGP_KNOB(5) != 7)  // K is symmetric: half the bytes (debug key 5 = 7: plain GEMV)
+        NNGP_TRY(launch_symv_f64(k64, ld, n, w.p, w.q, reg, w.symv_part, w.symv_np, s));
+    else
+        NNGP_TRY(launch_gemv_f64(k64, ld, n, n, w.p, 1, w.q, 1, reg, s));
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.p, w.q, n, w.scal + 1);  // pAp
     hipLaunchKernelGGL(k_pcg_update_xr, dim3(blocks256(n)), dim3(256), 0, s, xcol, w.r, w.p, w.q, n, w.scal);
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.r, n, rr_out);
