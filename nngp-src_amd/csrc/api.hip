@@ -141,7 +141,7 @@ struct nngp_model {
         dev_free(x); dev_free(y); dev_free(q); dev_free(kdiag); dev_free(k64); dev_free(a32); dev_free(dinv);
         dev_free(clamped); dev_free(alpha);
         dev_free(pcg.r); dev_free(pcg.z); dev_free(pcg.p); dev_free(pcg.q); dev_free(pcg.xcol); dev_free(pcg.bcol);
-        dev_free(pcg.f32a); dev_free(pcg.f32b); dev_free(pcg.f32c); dev_free(pcg.scal); dev_free(pcg.symv_part);
+        dev_free(pcg.f32a); dev_free(pcg.f32b); dev_free(pcg.f32c); dev_free(pcg.scal); dev_free(pcg.symv_part); dev_free(pcg.dot_part); dev_free(pcg.dot_ctr);
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
@@ -504,6 +504,9 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     A(dev_alloc(&m->pcg.f32a, np)); A(dev_alloc(&m->pcg.f32b, np)); A(dev_alloc(&m->pcg.f32c, np));
     A(dev_alloc(&m->pcg.scal, 32));
     A(dev_alloc(&m->pcg.symv_part, (np / TB) * np));
+    A(dev_alloc(&m->pcg.dot_part, 32));
+    A(dev_alloc(&m->pcg.dot_ctr, 1));
+    if (rc == 0 && hipMemset(m->pcg.dot_ctr, 0, sizeof(unsigned)) != hipSuccess) rc = -1;
     m->pcg.symv_np = np;
     {
         const int64_t bs_cap = triinv_block(np);

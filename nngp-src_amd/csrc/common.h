@@ -213,6 +213,8 @@ int launch_gemv_f64(const double* a, int64_t lda, int64_t rows, int64_t cols, co
 struct PcgWork {
     double* r; double* z; double* p; double* q; double* xcol; double* bcol;
     float* f32a; float* f32b; float* f32c;
+    double* dot_part = nullptr;   // [32] partial sums of the dot-product kernel
+    unsigned* dot_ctr = nullptr;  // its arrival counter (wraps to 0 by itself)
     double* symv_part = nullptr;  // [np / 128][np]: per-tile partial results of the symmetric matrix-vector product
     int64_t symv_np = 0;          // its np (0: not allocated -> plain GEMV)
     double* scal;       // device scalars [32]: 0..4 CG scalars, 6..7 trace / max of the diagonal, 8.. CG residual history

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void k_transpose_blocks(const float* __restric
 // One workgroup per 128 x 128 tile (I >= J) of the lower triangle: u = A_IJ x_J goes to part[J][rows of I] and, off the
 // diagonal, v = A_IJ^T x_I to part[I][rows of J] -- every (block, rows) slot of `part` is written by exactly one tile, and
 // k_symv_reduce sums a row's slots in a fixed order.  Wave w owns rows 32 w .. 32 w + 31 of the tile, lane l columns l and 64 + l.
-__global__ __launch_bounds__(256) void k_symv_tiles_f64(const double* __restrict__ A, int64_t lda, int64_t n,
+// At most 64 registers (__launch_bounds__(256, 8)): the kernel then fits into the wave slot that the posterior's float64 GEMM
+// leaves free on every SIMD and runs beside it instead of waiting for one of its workgroups to retire.
+__global__ __launch_bounds__(256, 8) void k_symv_tiles_f64(const double* __restrict__ A, int64_t lda, int64_t n,
                                                         const double* __restrict__ x, double* __restrict__ part, int64_t np) {
     __shared__ double xs[2][128];
     __shared__ double us[128];
@@ -111,23 +113,23 @@ __global__ __launch_bounds__(256) void k_symv_tiles_f64(const double* __restrict
     const double xj0 = xs[1][lane], xj1 = xs[1][64 + lane];
     double v0 = 0.0, v1 = 0.0;
 #pragma unroll 1
-    for (int r8 = 0; r8 < 32; r8 += 8) {
-        double a0[8], a1[8];
+    for (int r4 = 0; r4 < 32; r4 += 4) {
+        double a0[4], a1[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {  // eight rows' loads in flight
-            const int64_t r = I * 128 + wave * 32 + r8 + e;
+        for (int e = 0; e < 4; ++e) {  // four rows' loads in flight per wave (more would not fit 64 registers)
+            const int64_t r = I * 128 + wave * 32 + r4 + e;
             const double* ar = A + r * lda;
             a0[e] = (r < n && ok0) ? ar[c0] : 0.0;
             a1[e] = (r < n && ok1) ? ar[c1] : 0.0;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const double xi = xs[0][wave * 32 + r8 + e];
+        for (int e = 0; e < 4; ++e) {
+            const double xi = xs[0][wave * 32 + r4 + e];
             v0 = fma(a0[e], xi, v0);
             v1 = fma(a1[e], xi, v1);
             double sdot = fma(a0[e], xj0, a1[e] * xj1);
             for (int off = 32; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off);
-            if (lane == 0) us[wave * 32 + r8 + e] = sdot;
+            if (lane == 0) us[wave * 32 + r4 + e] = sdot;
         }
     }
     vs[wave][lane] = v0;
@@ -185,17 +187,30 @@ __global__ __launch_bounds__(256) void k_gemv_f64(const double* __restrict__ A, 
 
 // ---- small float64 vector kernels with device-resident scalars ----
 // scal[0] = rz, scal[1] = pAp, scal[2] = rz_new, scal[3] = |r|^2, scal[4] = |b|^2
-__global__ __launch_bounds__(1024) void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
-                                              double* out) {
-    __shared__ double red[16];
+// a . b in a fixed summation order.  kDotBlocks workgroups of 256 threads (NOT one of 1024: beside the posterior's float64
+// GEMM, whose two workgroups per CU leave one wave slot of <= 64 registers per SIMD, a 16-wave workgroup waited for a
+// GEMM workgroup to retire -- 0.7 ms on average, up to 4.8, per dot product, three per CG iteration); the last workgroup to
+// finish (wrapping atomic counter) adds the partial sums in block order.  part / counter: per-model scratch (PcgWork).
+constexpr int kDotBlocks = 32;
+__global__ __launch_bounds__(256, 8) void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                                double* out, double* part, unsigned* counter) {
+    __shared__ double red[4];
+    __shared__ bool last;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) s = fma(a[i], b[i], s);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kDotBlocks * 256) s = fma(a[i], b[i], s);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
+        part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicInc(counter, kDotBlocks - 1) == kDotBlocks - 1;  // wraps to 0: ready for the next call
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
         double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += red[w];
+        for (int w = 0; w < kDotBlocks; ++w) t += __hip_atomic_load(&part[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *out = t;
     }
 }
@@ -448,16 +463,16 @@ int pcg_iteration(const double* k64, int64_t ld, int64_t n, double reg, const fl
     NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, w.f32b, s));
     NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32b, w.f32c, s));
     hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32c, w.z, n);
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.z, n, w.scal + 2);  // rz_new
+    hipLaunchKernelGGL(k_dot, dim3(kDotBlocks), dim3(256), 0, s, w.r, w.z, n, w.scal + 2, w.dot_part, w.dot_ctr);  // rz_new
     hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks256(n)), dim3(256), 0, s, w.p, w.z, n, w.scal, it == 0);
     hipLaunchKernelGGL(k_scal_shift, dim3(1), dim3(1), 0, s, w.scal);  // rz = rz_new
     if (w.symv_part != nullptr && w.symv_np >= np && NNGP_KNOB(5) != 7)  // K is symmetric: half the bytes (debug key 5 = 7: plain GEMV)
         NNGP_TRY(launch_symv_f64(k64, ld, n, w.p, w.q, reg, w.symv_part, w.symv_np, s));
     else
         NNGP_TRY(launch_gemv_f64(k64, ld, n, n, w.p, 1, w.q, 1, reg, s));
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.p, w.q, n, w.scal + 1);  // pAp
+    hipLaunchKernelGGL(k_dot, dim3(kDotBlocks), dim3(256), 0, s, w.p, w.q, n, w.scal + 1, w.dot_part, w.dot_ctr);  // pAp
     hipLaunchKernelGGL(k_pcg_update_xr, dim3(blocks256(n)), dim3(256), 0, s, xcol, w.r, w.p, w.q, n, w.scal);
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, w.r, w.r, n, rr_out);
+    hipLaunchKernelGGL(k_dot, dim3(kDotBlocks), dim3(256), 0, s, w.r, w.r, n, rr_out, w.dot_part, w.dot_ctr);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -468,7 +483,7 @@ int pcg_begin(const double* k64, int64_t ld, int64_t n, double reg, const float*
     NNGP_REQUIRE(ahead >= 0 && ahead <= kPcgMaxAhead, "pcg_begin: at most %d iterations ahead", kPcgMaxAhead);
     NNGP_HIP_CHECK(hipMemsetAsync(xcol, 0, sizeof(double) * n, s));
     NNGP_HIP_CHECK(hipMemcpyAsync(w.r, bcol, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, bcol, bcol, n, w.scal + kPcgHist);
+    hipLaunchKernelGGL(k_dot, dim3(kDotBlocks), dim3(256), 0, s, bcol, bcol, n, w.scal + kPcgHist, w.dot_part, w.dot_ctr);
     for (int it = 0; it < ahead; ++it)
         NNGP_TRY(pcg_iteration(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, it, w.scal + kPcgHist + 1 + it, s));
     NNGP_HIP_CHECK(hipMemcpyAsync(w.host_scal + kPcgHist, w.scal + kPcgHist, sizeof(double) * (1 + ahead), hipMemcpyDeviceToHost, s));
