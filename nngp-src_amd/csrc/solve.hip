@@ -466,7 +466,9 @@ int pcg_iteration(const double* k64, int64_t ld, int64_t n, double reg, const fl
     hipLaunchKernelGGL(k_dot, dim3(kDotBlocks), dim3(256), 0, s, w.r, w.z, n, w.scal + 2, w.dot_part, w.dot_ctr);  // rz_new
     hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks256(n)), dim3(256), 0, s, w.p, w.z, n, w.scal, it == 0);
     hipLaunchKernelGGL(k_scal_shift, dim3(1), dim3(1), 0, s, w.scal);  // rz = rz_new
-    if (w.symv_part != nullptr && w.symv_np >= np && NNGP_KNOB(5) != 7)  // K is symmetric: half the bytes (debug key 5 = 7: plain GEMV)
+    // K is symmetric: half the bytes (debug key 5 = 7: plain GEMV).  Small fits keep the one-launch GEMV: the product is
+    // launch-bound there (N = 1000: +0.1 ms per predict with the two-launch form).
+    if (w.symv_part != nullptr && w.symv_np >= np && n >= 4096 && NNGP_KNOB(5) != 7)
         NNGP_TRY(launch_symv_f64(k64, ld, n, w.p, w.q, reg, w.symv_part, w.symv_np, s));
     else
         NNGP_TRY(launch_gemv_f64(k64, ld, n, n, w.p, 1, w.q, 1, reg, s));
