@@ -246,6 +246,10 @@ int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const fl
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                      const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                      void* stream);
+/* y = (A + diag_add I) x for a symmetric n x n float64 matrix stored in full (leading dimension lda), read from its LOWER
+ * triangle only: the product of the alpha CG (half the bytes of a plain GEMV, fixed summation order).  Any n >= 1; what
+ * lies beyond row / column n in a padded buffer is never read. */
+int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,
                       int64_t n, void* stream);

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_factor_shift", "nngp_model_prepare_serving", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode", "nngp_comm_unique_id", "nngp_comm_create", "nngp_comm_destroy", "nngp_comm_library",
-    "nngp_allgather_rows", "nngp_bcast", "nngp_model_update_timer", "nngp_model_update_timer_read",
+    "nngp_allgather_rows", "nngp_bcast", "nngp_model_update_timer", "nngp_model_update_timer_read", "nngp_symv_f64",
 )
 
 
@@ -125,6 +125,7 @@ def bind_prototypes(lib, knobs: bool = False):
     lib.nngp_comm_library.restype = ctypes.c_char_p
     lib.nngp_allgather_rows.argtypes = [vp, i64, i64, i32, vp, vp]
     lib.nngp_bcast.argtypes = [vp, i64, i32, i32, vp, vp]
+    lib.nngp_symv_f64.argtypes = [vp, i64, i64, vp, vp, dbl, vp]
     lib.nngp_model_update_timer.argtypes = [vp, i32]
     lib.nngp_model_update_timer_read.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     for name in ABI_SYMBOLS:

@@ -1308,6 +1308,17 @@ int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
     return launch_gemm_nt_f64(c, ldc, cin, ldcin, a, lda, b, ldb, m, n, k, alpha, beta, (hipStream_t)stream);
 }
 
+int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(a != nullptr && x != nullptr && y != nullptr && n > 0 && lda >= n, "symv_f64: bad arguments");
+    const int64_t np = round_up(n, TB);
+    double* part = nullptr;
+    NNGP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&part), sizeof(double) * (size_t)(np / TB) * np, s));
+    const int rc = launch_symv_f64(a, lda, n, x, y, diag_add, part, np, s);
+    NNGP_HIP_CHECK(hipFreeAsync(part, s));
+    return rc;
+}
+
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n,
                       void* stream) {
     NNGP_REQUIRE(b != nullptr && l != nullptr && dinv != nullptr, "trsm_rlt_f32: NULL argument");

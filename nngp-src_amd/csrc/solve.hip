@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 8) void k_symv_tiles_f64(const double* __restr
     }
     __syncthreads();
     const int64_t c0 = J * 128 + lane, c1 = c0 + 64;
-    const bool ok0 = c0 < n, ok1 = c1 < n;
+    const bool ok0 = c0 < n, ok1 = c1 < n, diag = (I == J);
     const double xj0 = xs[1][lane], xj1 = xs[1][64 + lane];
     double v0 = 0.0, v1 = 0.0;
 #pragma unroll 1
@@ -119,14 +119,16 @@ __global__ __launch_bounds__(256, 8) void k_symv_tiles_f64(const double* __restr
         for (int e = 0; e < 4; ++e) {  // four rows' loads in flight per wave (more would not fit 64 registers)
             const int64_t r = I * 128 + wave * 32 + r4 + e;
             const double* ar = A + r * lda;
-            a0[e] = (r < n && ok0) ? ar[c0] : 0.0;
-            a1[e] = (r < n && ok1) ? ar[c1] : 0.0;
+            // a diagonal tile is used from its lower triangle only, like the matrix as a whole
+            a0[e] = (r < n && ok0 && !(diag && c0 > r)) ? ar[c0] : 0.0;
+            a1[e] = (r < n && ok1 && !(diag && c1 > r)) ? ar[c1] : 0.0;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            const int64_t r = I * 128 + wave * 32 + r4 + e;
             const double xi = xs[0][wave * 32 + r4 + e];
-            v0 = fma(a0[e], xi, v0);
-            v1 = fma(a1[e], xi, v1);
+            v0 = fma((diag && c0 >= r) ? 0.0 : a0[e], xi, v0);  // transposed part: strictly below the diagonal there
+            v1 = fma((diag && c1 >= r) ? 0.0 : a1[e], xi, v1);
             double sdot = fma(a0[e], xj0, a1[e] * xj1);
             for (int off = 32; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off);
             if (lane == 0) us[wave * 32 + r4 + e] = sdot;
@@ -136,8 +138,9 @@ __global__ __launch_bounds__(256, 8) void k_symv_tiles_f64(const double* __restr
     vs[wave][64 + lane] = v1;
     __syncthreads();
     if (tid < 128) {
-        part[J * np + I * 128 + tid] = us[tid];
-        if (I != J) part[I * np + J * 128 + tid] = (vs[0][tid] + vs[1][tid]) + (vs[2][tid] + vs[3][tid]);
+        const double vt = (vs[0][tid] + vs[1][tid]) + (vs[2][tid] + vs[3][tid]);
+        part[J * np + I * 128 + tid] = diag ? us[tid] + vt : us[tid];
+        if (!diag) part[I * np + J * 128 + tid] = vt;
     }
 }
 

@@ -344,6 +344,7 @@ int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clampe
 int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n, int64_t k, float alpha, float beta, int32_t lower_only, void* stream) { (void)c; (void)ldc; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)lower_only; (void)stream; NOT_HERE("nngp_gemm_nt_f32"); }
 int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n, int64_t k, float alpha, float beta, float scale, int32_t lower_only, void* stream) { (void)c; (void)ldc; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)scale; (void)lower_only; (void)stream; NOT_HERE("nngp_gemm_nt_h3"); }
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda, const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, void* stream) { (void)c; (void)ldc; (void)cin; (void)ldcin; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)stream; NOT_HERE("nngp_gemm_nt_f64"); }
+int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream) { (void)a; (void)lda; (void)n; (void)x; (void)y; (void)diag_add; (void)stream; NOT_HERE("nngp_symv_f64"); }
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n, void* stream) { (void)b; (void)ldb; (void)m; (void)l; (void)ldl; (void)dinv; (void)n; (void)stream; NOT_HERE("nngp_trsm_rlt_f32"); }
 int nngp_comm_unique_id(void* id128) { (void)id128; NOT_HERE("nngp_comm_unique_id"); }
 int nngp_comm_create(nngp_comm** out, const void* id128, int32_t world, int32_t rank) { (void)out; (void)id128; (void)world; (void)rank; NOT_HERE("nngp_comm_create"); }

@@ -375,3 +375,32 @@ def test_hip_build_and_host_build_of_the_abi_agree(get):
     _, cov_h = hip.predict(xt, cov="full")
     _, cov_c = cpu.predict(xt, "full")
     np.testing.assert_allclose(cov_h, cov_c, rtol=1e-3, atol=1e-6 * np.abs(cov_c).max())
+
+
+@pytest.mark.parametrize("n,ld", [(1, 8), (127, 128), (128, 160), (1000, 1024), (4133, 4224)])
+def test_symmetric_product_reads_the_lower_triangle_only(n, ld):
+    """nngp_symv_f64 (the alpha CG's product): y = (A + c I) x from the lower triangle of a symmetric matrix held in a padded
+    buffer.  The strict upper triangle and everything beyond row / column n are poisoned with NaN: they must not be read."""
+    import torch
+    from nngp_src_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(n)
+    b = torch.randn((n, n), generator=g, dtype=torch.float64)
+    a = (b + b.T) / 2
+    x = torch.randn((n,), generator=g, dtype=torch.float64)
+    want = a @ x + 0.75 * x
+    rows = ((n + 127) // 128) * 128
+    buf = torch.full((rows, ld), float("nan"), dtype=torch.float64)
+    buf[:n, :n] = torch.tril(a) + torch.triu(torch.full((n, n), float("nan"), dtype=torch.float64), diagonal=1)
+    dev = _lib.require_gpu()
+    buf_d, x_d = buf.to(dev), x.to(dev)
+    y_d = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    _lib.check(lib.nngp_symv_f64(_lib.ptr(buf_d), ld, n, _lib.ptr(x_d), _lib.ptr(y_d), 0.75, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    y = y_d.cpu()
+    assert torch.isfinite(y).all()
+    assert float((y - want).abs().max()) <= 1e-12 * float(want.abs().max() + 1.0) * max(1.0, n ** 0.5)
+    y2 = torch.empty_like(y_d)
+    _lib.check(lib.nngp_symv_f64(_lib.ptr(buf_d), ld, n, _lib.ptr(x_d), _lib.ptr(y2), 0.75, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(y2.cpu(), y)  # fixed summation order
