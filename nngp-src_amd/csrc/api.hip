@@ -535,7 +535,8 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         m->split.col_stride = m->split.rows_cap * m->split.k_cap * 4;
         const int64_t ncols = (np + kLookAheadNb - 1) / kLookAheadNb;
         rc = dev_alloc(&m->split.planes, ncols * m->split.col_stride);
-        if (rc == 0) rc = dev_alloc(&m->split.counters, 8);
+        if (rc == 0) rc = dev_alloc(&m->split.counters, 16);
+        if (rc == 0 && hipMemset(m->split.counters, 0, 16 * sizeof(int)) != hipSuccess) rc = -1;
         if (rc == 0) rc = dev_alloc(&m->split.ldiag, kLookAheadNb * kLookAheadNb * 4);
         if (rc == 0) rc = dev_alloc(&m->split.dfrag, kLookAheadNb * 128);
     }

@@ -196,7 +196,16 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const
         __syncthreads();
         const int slot = s_slot;
         __syncthreads();  // s_slot may be rewritten only after every wave has read it
-        if (slot >= slots_per_xcd) break;
+        if (slot >= slots_per_xcd) {
+            // The work counters reset themselves: the last workgroup to run out of work (every other one has taken its final
+            // slot by then) zeroes them for the next launch -- no memset kernel in front of every launch (5 us each, ~130 per fit
+            // and predict at N = 32768).  counters[8] counts the workgroups that are done.
+            // (No fence: this thread's own slot fetches have returned their values before it counts itself done, and the end
+            // of the kernel publishes the zeros; an agent-scope release here would write back the XCD's L2.)
+            if (tid == 0 && atomicAdd(&counters[8], 1) == (int)gridDim.x - 1)
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(&counters[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         int bi, bj;
         {
             const int per = order_br * order_bc;
@@ -392,8 +401,8 @@ int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, floa
 }
 
 // a, b: split rows (row stride ldp bytes); rows of a / b up to the next multiple of 256 must be readable (their
-// products are never stored).  m, n multiples of 128; k a multiple of 32.  counters: 8 device ints owned by the caller
-// (zeroed here, on the stream).  reserve_cus: compute units left free for other streams (the grid is one workgroup
+// products are never stored).  m, n multiples of 128; k a multiple of 32.  counters: 16 device ints owned by the caller,
+// zero before the first launch (the kernel leaves them zero again).  reserve_cus: compute units left free for other streams (the grid is one workgroup
 // per remaining unit).
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
@@ -428,7 +437,6 @@ int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64
     if (grid > slots_per_xcd * 8) grid = slots_per_xcd * 8;
     grid = (grid / 8) * 8;  // the same number of workgroups on every XCD
     if (grid < 8) grid = 8;
-    NNGP_HIP_CHECK(hipMemsetAsync(counters, 0, 8 * sizeof(int), s));
     if (lower_only)
         hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
                            (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters, (int)slots_per_xcd,
