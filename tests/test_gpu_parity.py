@@ -295,11 +295,18 @@ def test_potrf_against_lapack(n):
         assert np.abs(Xb @ Lb - np.eye(128)).max() < 2e-3
 
 
-def test_potrf_flags_indefinite():
-    a = torch.eye(128, device=G.dev())
-    a[5, 5] = -1.0
-    _, clamped = G.potrf(a)
+@pytest.mark.parametrize("pos", [5, 31, 32, 70, 100, 127])
+def test_potrf_flags_indefinite(pos):
+    """A non-positive pivot is clamped and counted, whichever wave of the leaf leads its 32-column sub-block (the follower
+    waves recompute the clamped pivot from the published column and must arrive at the same factor); the rest stays finite."""
+    a = torch.eye(128, device=G.dev()) * 2.0
+    a[pos, pos] = -1.0
+    dinv, clamped = G.potrf(a)
     assert clamped >= 1
+    assert torch.isfinite(torch.tril(a)).all() and torch.isfinite(dinv).all()
+    keep = [i for i in range(128) if i != pos]
+    L = torch.tril(a).double().cpu().numpy()
+    assert np.allclose(np.diag(L)[keep], np.sqrt(2.0), rtol=1e-6)
 
 
 def test_trsm_right_lower_transposed():
