@@ -124,6 +124,7 @@ struct nngp_model {
     // HBM-bound CG (float64 GEMV + float32 TRSVs) overlaps the MFMA-bound covariance products.
     hipStream_t solve_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
+    hipEvent_t ev_lt = nullptr;  // orders the split copy of L^T written on solve_stream (apply_inverse_f32)
     hipEvent_t ev_predict = nullptr;  // end of the last predict on its stream: it reads alpha and the CG residual
     bool have_predict_event = false;
     bool solve_pending = false;
@@ -147,6 +148,7 @@ struct nngp_model {
         lookahead_destroy(la);
         if (solve_stream) (void)hipStreamDestroy(solve_stream);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
@@ -319,7 +321,18 @@ int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
 
 // b32 [mp, np] <- b32 (L L^T)^-1
 int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    // The split copy of L^T (first covariance predict after a fit) is only read by the second half: it is written on the
+    // model's own stream (idle until the alpha CG is asked for) beside the forward solve.  (debug key 2 = 7: in stream order)
+    const bool lt_aside = NNGP_KNOB(7) != 1 && use_split_solves(m, mp) && !m->split.lt_ready && m->split.planes_t != nullptr &&
+                          m->ev_lt != nullptr && NNGP_KNOB(2) != 7;
+    if (lt_aside) {
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_lt, s));
+        NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_lt, 0));
+        NNGP_TRY(ensure_lt_split(m, m->solve_stream));
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_lt, m->solve_stream));
+    }
     NNGP_TRY(apply_forward_f32(m, mp, s));
+    if (lt_aside) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_lt, 0));
     if (NNGP_KNOB(7) == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
     if (use_split_solves(m, mp)) {
         NNGP_TRY(ensure_lt_split(m, s));
@@ -523,6 +536,7 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
     if (rc == 0 && (hipStreamCreateWithPriority(&m->solve_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
                     hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_lt, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&m->ev_solved, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&m->ev_predict, hipEventDisableTiming) != hipSuccess)) {
         set_error("model_create: could not create the solve stream");
