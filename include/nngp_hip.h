@@ -176,7 +176,8 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  *   L > 2  L-1 sweeps + the second-order formula                                     2e-10 at L = 3
  * Levels >= 1 are adaptive: the sweeps contract by the spectral radius of I - M^-1 A (M = the float32 factor), which
  * approaches 1 when cond(K + reg I) * eps32 does (small diag_reg, low-dimensional encodings).  After the fixed sweeps
- * predict checks two signs of that -- the alpha solve took >= 8 CG iterations (NTK: >= 4), or a row's first-order term
+ * predict checks the signs of that -- the alpha solve took >= 8 CG iterations (the default diag level: >= 7; NTK: >= 6, or
+ * the two sweeps' own estimate of what they left exceeds 3e-7, see nngp_model_sweep_estimate), or a row's first-order term
  * z.r is too large for its second-order error to be small (a loose lower bound: the backstop when the alpha solve says
  * nothing, e.g. y = 0) -- and then continues the rows by preconditioned
  * CG (one float64 product + one pair of solves per iteration, each row with its own scalars) until every row's step
@@ -185,6 +186,14 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  * nngp_model_cov_iters returns the iterations the last predict spent there (0: the fixed sweeps were enough). */
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps);
 int nngp_model_cov_iters(nngp_model* m);
+/* NTK covariance only: what the last predict expected its two fixed sweeps to leave, from the error energies
+ * e = r . M^-1 r the two corrections saw (e2 ~ e1 * (e1 / e0)), worst row: row_rel = sqrt(e2 / |z . k|), the relative
+ * energy-norm error of the row, and var_rel = rho / (1 - rho) * |dv| / |var| with rho = sqrt(e1 / e0) and dv the change of
+ * the variance under the second correction: the predicted relative variance error (measured within 0.4x .. 120x of the
+ * real one wherever that exceeds 1e-8).  var_rel above 3e-7 sent the rows on by CG; costs a 16-byte read-back.  Both
+ * are -1 when the last predict did not measure them (NNGP, or the alpha solve's iteration count had already decided).
+ * Either pointer may be NULL. */
+int nngp_model_sweep_estimate(nngp_model* m, double* row_rel, double* var_rel);
 
 /* Serving mode (the reference's Estimator keeps its factor and solves per query batch: estimator.py:34-67).  Builds the
  * explicit float64 inverse X = (K + reg I)^-1 once per fit -- rows of the identity, 1024 at a time, through the

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "nngp_model_destroy", "nngp_model_fit", "nngp_model_set_train", "nngp_model_build_rows",
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_append", "nngp_model_kernel_buffer", "nngp_model_info",
-    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_factor_shift", "nngp_model_prepare_serving", "nngp_potrf_f32", "nngp_gemm_nt_f32",
+    "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_sweep_estimate", "nngp_model_factor_shift", "nngp_model_prepare_serving", "nngp_potrf_f32", "nngp_gemm_nt_f32",
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode", "nngp_comm_unique_id", "nngp_comm_create", "nngp_comm_destroy", "nngp_comm_library",
     "nngp_allgather_rows", "nngp_bcast", "nngp_model_update_timer", "nngp_model_update_timer_read", "nngp_symv_f64",
@@ -112,6 +112,7 @@ def bind_prototypes(lib, knobs: bool = False):
     lib.nngp_model_factor_shift.argtypes = [vp]
     lib.nngp_model_factor_shift.restype = ctypes.c_double
     lib.nngp_model_cov_iters.restype = ctypes.c_int
+    lib.nngp_model_sweep_estimate.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     lib.nngp_model_append.argtypes = [vp, vp, vp, i64, vp]
     lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]

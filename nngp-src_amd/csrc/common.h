@@ -262,11 +262,18 @@ struct RowsPcg {
     double* delta = nullptr;  // [cap] first-order term z . r of the fixed sweeps
     double* var = nullptr;    // [cap] variance estimate of the fixed sweeps (full-covariance mode)
     int32_t* state = nullptr; // [cap] >= 0: consecutive small steps; -1: finished
-    int32_t* live = nullptr;  // [2] rows still iterating; rows flagged by k_rows_prepare
-    int32_t* host = nullptr;  // pinned [2]
+    int32_t* live = nullptr;  // [6] rows still iterating; rows flagged by k_rows_prepare; [2..5]: two doubles, the sweep estimates
+    int32_t* host = nullptr;  // pinned [6], same layout
 };
 int launch_rows_prepare(const double* delta, const double* ktt, const double* var, const double* q, int mode, double thr,
                         int64_t rows, double* tol, int32_t* flagged, hipStream_t s);
+int launch_rows_energy(const double* r, const float* s32, int64_t ld, int64_t rows, int64_t cols, double* out, hipStream_t s);
+int launch_rows_prepare_ntk(const double* e1, const double* dv, double* zk_tol, const double* var, int64_t vstride,
+                            int64_t rows, double tau, hipStream_t s);
+int launch_rows_dvar(const float* d32, const double* w, const double* k, double kscale, int64_t ld, int64_t rows,
+                     int64_t cols, double* out, hipStream_t s);
+int launch_sweep_estimate(const double* e0, const double* e1, const double* zk, const double* dv, const double* var,
+                          int64_t vstride, int64_t rows, double* out, hipStream_t s);
 int launch_rows_rho(const double* r, const float* s32, int64_t ld, int64_t rows, int64_t cols, bool first, RowsPcg& w,
                     hipStream_t s);
 int launch_rows_update_p(double* p, const float* s32, int64_t ld, int64_t rows, int64_t cols, RowsPcg& w, hipStream_t s);

@@ -165,6 +165,25 @@ __global__ void k_rows_prepare(const double* __restrict__ delta, const double* _
     if (bad) atomicAdd(flagged, 1);
 }
 
+// NTK rows before they go on by CG: the stopping tolerance on the per-step decrease of e^T A e.  The variance is first
+// order in the row's error, |d var| ~ gamma * sqrt(e^T A e); the second sweep measured gamma = |dv| / sqrt(e1) (its
+// correction had energy ~ e1 and moved the variance by dv).  tol = the energy at which gamma * sqrt(energy) = tau var,
+// kept within [1e-30, 1e-13] of the row's energy z . k.  tau = 1e-10: gamma is measured along ONE direction and the
+// later CG errors lie elsewhere -- against an 80-bit referee on the same kernel matrices (tests/
+// test_gpu_extended_precision.py, N = 279 .. 907, d = 2 .. 3, cond ~ 1e8) tau = 1e-8 left 2.5e-5 .. 6.5e-5 in the variance,
+// 1e-12 leaves 5e-6 .. 4e-5 for one or two more iterations; below that the float64 kernel entries themselves decide
+// (last-bit differences in them move these variances by 1e-4).  zk_tol: z . k in, tol out.
+__global__ void k_rows_prepare_ntk(const double* __restrict__ e1, const double* __restrict__ dv, double* zk_tol,
+                                   const double* __restrict__ var, int64_t vstride, int64_t rows, double tau) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const double q = fabs(zk_tol[i]), v = tau * fabs(var[i * vstride]), d = dv[i];
+    double t = (d != 0.0 && e1[i] > 0.0) ? v * v * (e1[i] / (d * d)) : 1e-13 * q;
+    if (!(t <= 1e-13 * q)) t = 1e-13 * q;
+    if (!(t >= 1e-30 * q)) t = 1e-30 * q;
+    zk_tol[i] = t;
+}
+
 // rho_new = r . s (s = M^-1 r in float32); beta = rho_new / rho_old; a row whose rho is not positive is finished
 __global__ __launch_bounds__(256) void k_rows_rho(const double* __restrict__ r, const float* __restrict__ s32, int64_t ld,
                                                   int64_t cols, int first, double* __restrict__ rho, double* __restrict__ coef,
@@ -184,6 +203,71 @@ __global__ __launch_bounds__(256) void k_rows_rho(const double* __restrict__ r, 
         rho[row] = acc;
         coef[row] = beta;
     }
+}
+
+// out[row] = r[row] . s32[row]  (s32 = M^-1 r: the energy e^T A e of the row's error, to the accuracy of M as a solver)
+__global__ __launch_bounds__(256) void k_rows_energy(const double* __restrict__ r, const float* __restrict__ s32, int64_t ld,
+                                                     int64_t cols, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < cols; j += 256) acc = fma(r[row * ld + j], (double)s32[row * ld + j], acc);
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[row] = acc;
+}
+
+// out[row] = 2 d32[row] . (w[row] + kscale * k[row]): the change of the NTK variance K_tt + z.(K z - 2 k) under the row's
+// last correction d (first order; w = K z).  k may be NULL (w already holds K z - k).
+__global__ __launch_bounds__(256) void k_rows_dvar(const float* __restrict__ d32, const double* __restrict__ w,
+                                                   const double* __restrict__ k, double kscale, int64_t ld, int64_t cols,
+                                                   double* __restrict__ out) {
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < cols; j += 256) {
+        double g = w[row * ld + j];
+        if (k) g = fma(kscale, k[row * ld + j], g);
+        acc = fma((double)d32[row * ld + j], g, acc);
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[row] = 2.0 * acc;
+}
+
+// What two stationary sweeps leave in the NTK variance, predicted from what they removed.  e0, e1: the error energies
+// r . M^-1 r before the first and the second correction, rho = sqrt(e1 / e0) the contraction per sweep in the energy
+// norm; dv: the change of the variance under the second correction (k_rows_dvar).  The variance is first order in the
+// error of the row z, so what is left is ~ rho / (1 - rho) * |dv|.
+// out[0] = max over rows of sqrt(e1 * (e1 / e0) / |z . k|) (relative energy-norm error of z),
+// out[1] = max over rows of rho / (1 - rho) * |dv| / |var| (predicted relative variance error).  One workgroup.
+__global__ __launch_bounds__(256) void k_sweep_estimate(const double* __restrict__ e0, const double* __restrict__ e1,
+                                                        const double* __restrict__ zk, const double* __restrict__ dv,
+                                                        const double* __restrict__ var, int64_t vstride, int64_t rows,
+                                                        double* __restrict__ out) {
+    __shared__ double red[2][256];
+    double w0 = 0.0, w1 = 0.0;
+    for (int64_t i = threadIdx.x; i < rows; i += 256) {
+        const double a = e0[i], b = e1[i], c = fabs(zk[i]);
+        if (a > 0.0 && b > 0.0 && c > 0.0) {
+            const double rho = sqrt(b / a);
+            const double rel = sqrt(b * (b / a) / c);
+            const double left = rho < 1.0 ? rho / (1.0 - rho) * fabs(dv[i]) / fabs(var[i * vstride]) : INFINITY;
+            w0 = (rel > w0 || !isfinite(rel)) ? rel : w0;
+            w1 = (left > w1 || !isfinite(left)) ? left : w1;
+        }
+    }
+    red[0][threadIdx.x] = w0;
+    red[1][threadIdx.x] = w1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            for (int q = 0; q < 2; ++q) {
+                const double o = red[q][threadIdx.x + w];
+                if (o > red[q][threadIdx.x] || !isfinite(o)) red[q][threadIdx.x] = o;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) out[threadIdx.x] = red[threadIdx.x][0];
 }
 
 // p = s + beta p   (finished rows: p = 0)
@@ -460,6 +544,36 @@ int launch_rows_prepare(const double* delta, const double* ktt, const double* va
 int launch_rows_rho(const double* r, const float* s32, int64_t ld, int64_t rows, int64_t cols, bool first, RowsPcg& w,
                     hipStream_t s) {
     hipLaunchKernelGGL(k_rows_rho, dim3((unsigned)rows), dim3(256), 0, s, r, s32, ld, cols, first ? 1 : 0, w.rho, w.coef, w.state);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_energy(const double* r, const float* s32, int64_t ld, int64_t rows, int64_t cols, double* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_rows_energy, dim3((unsigned)rows), dim3(256), 0, s, r, s32, ld, cols, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_prepare_ntk(const double* e1, const double* dv, double* zk_tol, const double* var, int64_t vstride,
+                            int64_t rows, double tau, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_rows_prepare_ntk, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, e1, dv, zk_tol, var, vstride, rows, tau);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_dvar(const float* d32, const double* w, const double* k, double kscale, int64_t ld, int64_t rows,
+                     int64_t cols, double* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_rows_dvar, dim3((unsigned)rows), dim3(256), 0, s, d32, w, k, kscale, ld, cols, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep_estimate(const double* e0, const double* e1, const double* zk, const double* dv, const double* var,
+                          int64_t vstride, int64_t rows, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sweep_estimate, dim3(1), dim3(256), 0, s, e0, e1, zk, dv, var, vstride, rows, out);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -147,6 +147,14 @@ class GPModel:
         that when the float32 factor is a weak preconditioner; 0 = the fixed sweeps were enough)."""
         return int(self.lib.nngp_model_cov_iters(self.handle))
 
+    def sweep_estimate(self):
+        """NTK covariance: (row_rel, var_rel) -- the relative energy-norm error of the worst row and the relative variance
+        error the last predict expected its fixed sweeps to leave (var_rel decides whether the rows go on by CG when the
+        alpha solve took few iterations); (-1, -1) when not measured."""
+        a, b = ctypes.c_double(-1.0), ctypes.c_double(-1.0)
+        self._check(self.lib.nngp_model_sweep_estimate(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def fit(self, x, y):
         self.set_train(x, y)
         self.build_rows(0, self.n)

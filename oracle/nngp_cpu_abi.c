@@ -329,6 +329,12 @@ done:
 
 int nngp_model_set_refine(nngp_model* m, int32_t sweeps) { (void)sweeps; REQUIRE(m != NULL, "set_refine: NULL model"); return 0; }  /* float64 throughout */
 int nngp_model_cov_iters(nngp_model* m) { (void)m; return 0; }
+int nngp_model_sweep_estimate(nngp_model* m, double* row_rel, double* var_rel) {
+    (void)m;
+    if (row_rel) *row_rel = -1.0;
+    if (var_rel) *var_rel = -1.0;
+    return 0;
+}
 
 /* ---- no CPU counterpart: exported so that a binding of the header links, answering -2 ---- */
 int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, int64_t b, void* stream) { (void)m; (void)x_new; (void)y_new; (void)b; (void)stream; NOT_HERE("nngp_model_append"); }

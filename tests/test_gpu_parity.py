@@ -678,7 +678,7 @@ def test_random_sweep_against_the_float64_oracle(seed):
     if os.environ.get("NNGP_SWEEP_LEVEL"):    # exploration: another covariance precision level
         model.set_refine(int(os.environ["NNGP_SWEEP_LEVEL"]))
     mean, var = model.predict(xt, cov="diag")  # before info(): the alpha CG stops early, the mean is corrected through Z
-    cov_iters = model.cov_iters()
+    cov_iters, sweep_est = model.cov_iters(), model.sweep_estimate()[1]
     info = model.info()
     shift = model.factor_shift() / info["reg"]
     _, cov = model.predict(xt[:64], cov="full")
@@ -698,7 +698,7 @@ def test_random_sweep_against_the_float64_oracle(seed):
         var_ref, alpha_ref = np.diag(cov_ref), post._factor("ntk")[2]
         reg_ref = c["diag_reg"] * (1.0 if c["absolute"] else np.trace(post._factor("ntk")[0]) / c["n"])
     l2, elem = G.mean_gate(mean, mean_ref)
-    row = dict(c, reg_rel=abs(info["reg"] - reg_ref) / reg_ref, cg_iters=info["refine_iters"], cov_iters=cov_iters, factor_shift=shift,
+    row = dict(c, reg_rel=abs(info["reg"] - reg_ref) / reg_ref, cg_iters=info["refine_iters"], cov_iters=cov_iters, sweep_est=sweep_est, factor_shift=shift,
                clamped=info["clamped_pivots"],
                alpha_rel_l2=G.rel_l2(model.alpha().cpu().numpy(), alpha_ref), mean_rel_l2=l2, mean_elem=elem,
                var_max_rel=float(np.max(np.abs(var - var_ref.ravel()) / np.maximum(np.abs(var_ref.ravel()), 1e-9 * np.abs(var_ref).max() + 1e-11 * prior))))
@@ -714,8 +714,14 @@ def test_random_sweep_against_the_float64_oracle(seed):
         assert cov_iters > 0 and row["var_max_rel"] < 1e-6, row  # weak preconditioner: the rows must have gone on by CG
     # small regularisers (1e-4 relative, or absolute on a large-trace kernel) raise cond(K + reg I): alpha itself is
     # then determined to ~cond * eps64 only, the mean stays at the gate
-    assert row["mean_rel_l2"] < 1e-6 and row["mean_elem"] < 1e-5, row
-    assert row["var_max_rel"] < 1e-4, row
+    # (gates of SURVEY.md 7: 1e-4 norm-wise and elementwise; 149 of 150 cases are within 1e-6 / 5e-6, the last -- seed 119,
+    # NTK, d = 2, four layers, cond ~ 1e8 -- at 7e-7 / 1.1e-5)
+    assert row["mean_rel_l2"] < 1e-6 and row["mean_elem"] < 3e-5, row
+    # Variance gate of SURVEY.md 7: 1e-3 relative.  Held here at 3e-4: the float64 oracle itself is that far from an 80-bit
+    # referee on the worst-conditioned cases (d = 2 .. 3, diag_reg 1e-4: rows whose variance is 1e-8 of the prior), and
+    # last-bit differences between the two kernel builds move those variances by 1e-4
+    # (tests/test_gpu_extended_precision.py; profiles/r2_extended_precision.jsonl).  143 of 150 cases are within 3e-5.
+    assert row["var_max_rel"] < 3e-4, row
 
 
 def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
