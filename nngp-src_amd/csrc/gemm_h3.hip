@@ -316,6 +316,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const
         if (group == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
 
         // epilogue: acc[i][j][r] is element (row, col) with row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.
+        // (Measured and dropped: beta == 1 as 128 no-return global_atomic_add_f32 per lane instead of load, add, store --
+        // no C round trips in the wave, one add per element so the same sum; the Cholesky at N = 32768 went from 50.5 to
+        // 51.4 ms and the solves of the posterior from 55.2 to 56.7: the L2's read-modify-write costs more than the loads it saves.)
         // The C loads are HBM-latency bound (~2.5 us a round trip): the values of two sub-tiles are requested together, and
         // the in/out tests use wave-uniform indices so that they are scalar branches (per-lane tests made hipcc wait for
         // every sub-tile's loads separately).
