@@ -404,3 +404,25 @@ def test_symmetric_product_reads_the_lower_triangle_only(n, ld):
     _lib.check(lib.nngp_symv_f64(_lib.ptr(buf_d), ld, n, _lib.ptr(x_d), _lib.ptr(y2), 0.75, _lib.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(y2.cpu(), y)  # fixed summation order
+
+
+@pytest.mark.parametrize("get,n,d", [("nngp", 6144, 32), ("ntk", 3072, 20)])
+def test_fit_and_predict_are_bitwise_reproducible(get, n, d):
+    """Two models, same inputs: alpha, means, variances and the full covariance are bit-identical.  Nothing on the path may
+    depend on which workgroup took which tile from the work counters, on the order partial sums arrive in (the CG's dot
+    products and symmetric product sum fixed slots in a fixed order), or on what an earlier fit left in the workspaces."""
+    x, y = synth.synthetic_queries(n, d, seed=31)
+    xt, _ = synth.synthetic_queries(700, d, seed=32)
+    outs = []
+    for rep in range(2):
+        model = GPModel(n, d, [1.1, 0.9, 1.0], [0.05, 0.0, 0.1], get=get, diag_reg=1e-3)
+        if rep == 1:  # a different fit first: stale workspace contents must not leak into the second one
+            model.fit(x[::-1].copy(), y[::-1].copy())
+            model.predict(xt[:100], cov="diag")
+        model.fit(x, y)
+        mean, var = model.predict(xt, cov="diag")
+        _, cov = model.predict(xt[:96], cov="full")
+        outs.append((model.alpha().cpu().numpy(), np.asarray(mean), np.asarray(var), np.asarray(cov), model.info()["refine_iters"]))
+        model.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
