@@ -667,6 +667,10 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
         const int64_t sup_r = (tiles_r + 7) / 8, sup_c = (tiles_c + 7) / 8;
         const int64_t nsup = a.sym ? sup_r * (sup_r + 1) / 2 : sup_r * sup_c;
         const int64_t grid = ((nsup + 7) / 8) * 8 * 64;  // 64 tile slots per super-tile, super-tiles dealt round-robin to 8 XCDs
+        // (Measured and dropped: a persistent grid of 3 workgroups per compute unit walking the slots -- the 133 k one-tile
+        // workgroups spend ~1.3 ms in dispatch and set-up when everything else is masked out -- took 7.95 ms against 6.97: the
+        // loop state costs 17 spilled registers at the 168 the occupancy allows, and the same body with one slot per
+        // workgroup already loses 0.45 ms to them.)
         NNGP_REQUIRE(grid < (int64_t)2147483647, "kernel_build: grid too large (%lld workgroups)", (long long)grid);
         const int ablate = NNGP_KNOB(3) >= 32 && NNGP_KNOB(3) < 40 ? NNGP_KNOB(3) - 32 : 0;  // timing ablations (wrong results)
         const int variant = NNGP_KNOB(5) >= 20 && NNGP_KNOB(5) < 30 ? NNGP_KNOB(5) - 20 : 0;  // A/B timing of the kernel forms
