@@ -1254,6 +1254,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // Then the rows go on by preconditioned CG until each has converged, and the covariance is formed again.
     // (debug key 6 = 1: fixed sweeps only.)
     m->cov_iters = 0;
+    m->sweep_est = m->sweep_est_var = -1.0;
     if (check_kind != 0 && NNGP_KNOB(6) != 1) {
         // Iterations of the alpha solve against the variance error of the fixed sweeps, 72 random fits of
         // tests/test_gpu_parity.py (N <= 5200): <= 5: <= 1e-7, 6: <= 1e-5, 7: <= 5e-5, >= 9: up to 8e-2; the bench sizes
@@ -1262,7 +1263,6 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         // threshold was 4 until round 2, which sent the N = 16384 bench config (4 iterations, 3.6e-8 after the sweeps) through
         // three continuation steps, 78 ms per predict instead of 37)
         bool weak = m->iters >= (is_ntk ? 6 : (check_kind == 4 ? 7 : 8)) || m->reg_fac > m->reg;
-        m->sweep_est = m->sweep_est_var = -1.0;
         if (!weak && check_kind == 3) {
             // NTK below 6 iterations: the count alone does not separate 4e-8 (N = 16384, d = 256: 4 iterations) from 5e-5
             // (N = 907, d = 2, four layers, diag_reg 1e-4: also 4).  What the two sweeps removed does: 16-byte read-back.
