@@ -159,6 +159,74 @@ def bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, 
     dist.destroy_process_group()
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher around it: start the ranks as a CHILD `torch.distributed.run` of this same
+    file with the same arguments, relay rank 0's JSON line and exit with the child's code.  Runs before this process has imported
+    torch or touched the GPU (a process that has initialised HIP must never exec or be replaced; a child process is fine)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    limit = float(os.environ.get("NNGP_BENCH_TIMEOUT", "3000"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, err = child.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)  # the process group this launcher started, nothing else
+        except ProcessLookupError:
+            pass
+        out, err = child.communicate()
+        sys.stderr.write(err[-4000:])
+        sys.stderr.write("\nbench.py: the %d-rank child run exceeded %.0f s and was killed\n" % (n_ranks, limit))
+        sys.exit(124)
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
+    if (child.returncode != 0 or line is None) and env.get("NNGP_COLLECTIVE", "native") == "native" and "--mode" not in sys.argv:
+        # one more attempt with every collective through torch.distributed's own RCCL process group instead of the library's
+        # communicator (a different configuration, named in the line) -- a crash there must not cost the whole measurement
+        sys.stderr.write(err[-3000:])
+        sys.stderr.write("\nbench.py: child run failed (code %d); second attempt with NNGP_COLLECTIVE=torch\n" % child.returncode)
+        env["NNGP_COLLECTIVE"] = "torch"
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            cmd[cmd.index("--master-port") + 1] = str(s.getsockname()[1])
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        try:
+            out, err = child.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.communicate()
+            sys.exit(124)
+        line = None
+        for ln in out.splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                d = json.loads(ln)
+                d["launcher_note"] = "first attempt (library-owned RCCL communicator) failed; this line is the NNGP_COLLECTIVE=torch run"
+                line = json.dumps(d)
+    if child.returncode != 0 or line is None:
+        sys.stderr.write(err[-6000:])
+        sys.stderr.write("\nbench.py: the %d-rank child run (%s) ended with code %d%s\n"
+                         % (n_ranks, " ".join(cmd[1:4]), child.returncode, "" if line else " and printed no result line"))
+        sys.exit(child.returncode or 1)
+    print(line, flush=True)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +239,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compare", action="store_true", help="multi-GPU: skip the untimed comparison legs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)  # no torch import, no GPU call before this point
 
     import torch
     import torch.distributed as dist
@@ -182,11 +252,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
     if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if world != args.gpus:
+            sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
         # NNGP_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
-        # devices, collectives staged through the host); the real runs use nccl = RCCL over xGMI.
-        backend = os.environ.get("NNGP_DIST_BACKEND", "nccl")
-        local_dev = local_rank % max(torch.cuda.device_count(), 1)
+        # devices, collectives staged through the host); the real runs use nccl = RCCL over xGMI.  RCCL refuses two ranks
+        # on one device, so with fewer devices than ranks the rehearsal backend is taken (and named in the line).
+        n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if n_dev < 1:
+            sys.exit("bench.py: no GPU visible")
+        backend = os.environ.get("NNGP_DIST_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+        local_dev = local_rank % n_dev
         torch.cuda.set_device(local_dev)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
@@ -228,12 +303,8 @@ def main():
             try:
                 comm = distributed.NativeComm()
                 collective = "libnngp_hip nngp_allgather_rows: ncclAllGather in place (%s)" % comm.library
-            except _lib.NngpError as e:  # every rank fails alike (same library, same box); recorded in the line
+            except _lib.NngpError as e:  # NativeComm's rendezvous is failure-symmetric: it raises on every rank or on none
                 collective += " [native RCCL communicator unavailable: %s]" % str(e)[:120]
-            flag = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                comm = None
 
     def ev():
         e = torch.cuda.Event(enable_timing=True)

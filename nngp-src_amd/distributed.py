@@ -43,23 +43,51 @@ class NativeComm:
     refuses two ranks on one device, so the gloo rehearsals on a single GPU cannot use it."""
 
     def __init__(self, group=None):
+        """Failure-symmetric rendezvous: every rank runs the SAME sequence of ``torch.distributed`` collectives whether or not
+        a step failed on it, and either every rank ends with a communicator or every rank raises ``NngpError`` -- a rank never
+        leaves the others inside a collective it skipped.  (1) each rank binds librccl, all agree (all_reduce MIN); (2) rank 0
+        creates the id and ALWAYS broadcasts 129 bytes = status + id; (3) ``ncclCommInitRank`` on every rank, all agree."""
         import ctypes
         import torch
         from . import _lib
         dist = _dist()
         self.lib = _lib.load()
+        self.handle = None
         self.world, self.rank = world_size(), rank()
-        ident = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            _lib.check(self.lib.nngp_comm_unique_id(ident), self.lib)
-        if self.world > 1:
-            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-            t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
-            dist.broadcast(t, src=0, group=group)
-            ident = ctypes.create_string_buffer(bytes(t.cpu().tolist()), 128)
-        self.handle = ctypes.c_void_p()
-        _lib.check(self.lib.nngp_comm_create(ctypes.byref(self.handle), ident, self.world, self.rank), self.lib)
+        multi = self.world > 1
+        dev = (torch.device("cuda", torch.cuda.current_device()) if multi and dist.get_backend(group) == "nccl"
+               else torch.device("cpu"))
+
+        def all_ok(ok: bool) -> bool:
+            if not multi:
+                return ok
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
         self.library = (self.lib.nngp_comm_library() or b"").decode()
+        mine = "" if self.library else (self.lib.nngp_last_error() or b"librccl not found").decode()
+        if not all_ok(bool(self.library)):
+            raise _lib.NngpError("RCCL could not be bound on every rank" + (": " + mine if mine else " (another rank failed)"))
+        ident = ctypes.create_string_buffer(128)
+        status, mine = 0, ""
+        if self.rank == 0 and self.lib.nngp_comm_unique_id(ident) != 0:
+            status, mine = 1, (self.lib.nngp_last_error() or b"").decode()
+        if multi:
+            t = torch.tensor([status] + list(ident.raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0, group=group)
+            raw = bytes(t.cpu().tolist())
+            status, ident = raw[0], ctypes.create_string_buffer(raw[1:], 128)
+        if status != 0:
+            raise _lib.NngpError("ncclGetUniqueId failed on rank 0" + (": " + mine if mine else ""))
+        handle = ctypes.c_void_p()
+        rc = self.lib.nngp_comm_create(ctypes.byref(handle), ident, self.world, self.rank)
+        mine = "" if rc == 0 else (self.lib.nngp_last_error() or b"").decode()
+        if not all_ok(rc == 0):
+            if rc == 0:
+                self.lib.nngp_comm_destroy(handle)
+            raise _lib.NngpError("ncclCommInitRank did not succeed on every rank" + (": " + mine if mine else " (another rank failed)"))
+        self.handle = handle
 
     def allgather_rows(self, buf, n: int):
         from . import _lib

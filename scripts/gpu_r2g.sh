@@ -38,7 +38,7 @@ timeout -k 10 300 python scripts/append_bench.py > $O/append_bench.json 2>/dev/n
 timeout -k 10 300 python scripts/var_study.py > $O/var_study.json 2>/dev/null
 timeout -k 10 200 python scripts/k1_variants.py 2>/dev/null | grep KC > $O/k1_variants.txt
 timeout -k 10 200 python scripts/k1_study.py > $O/k1_study.json 2>/dev/null
-./scripts/micro/f64_pipes > $O/micro_f64_pipes.txt 2>&1; ./scripts/micro/f64_seed_accuracy > $O/micro_f64_seed_accuracy.txt 2>&1
+make -C scripts/micro -s && ./scripts/micro/f64_pipes > $O/micro_f64_pipes.txt 2>&1; ./scripts/micro/f64_seed_accuracy > $O/micro_f64_seed_accuracy.txt 2>&1
 bash scripts/gpu_multirank_rehearsal.sh cfg2 2>&1 | tail -5; for g in 1 2 4; do cp gpurun_out/rehearsal_g$g.json $O/rehearsal_shard_cfg2_${g}ranks_gloo.json; done
 ab() {
   NNGP_DEBUG=$1 timeout -k 10 300 python bench.py --config $2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "

@@ -66,3 +66,19 @@ def test_sharded_kernel_allgather_gloo(tmp_path, world, n):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, 6, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_bench_self_launcher_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE starts its ranks as a child torch.distributed.run (the parent
+    never imports torch); on a host without a GPU the ranks stop with a message, nothing reaches stdout, and the parent returns the
+    failure.  (The successful two-rank line is tests/test_gpu_distributed.py::test_bench_launches_its_own_ranks.)"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU host: covered by the -m gpu test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["NNGP_COLLECTIVE"] = "torch"  # no second attempt: there is no GPU either way
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg1", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "no GPU visible" in r.stderr and "2-rank child run" in r.stderr

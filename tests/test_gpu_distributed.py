@@ -98,7 +98,8 @@ def test_native_rccl_communicator_single_rank():
     from nngp_src_amd import distributed, _lib
     torch.cuda.set_device(0)
     comm = distributed.NativeComm()
-    assert comm.world == 1 and comm.rank == 0 and "rccl" in comm.library.lower() or comm.library.startswith("symbols"), comm.library
+    assert comm.world == 1 and comm.rank == 0
+    assert "rccl" in comm.library.lower() or comm.library.startswith("symbols"), comm.library
     k = torch.arange(6 * 8, dtype=torch.float64, device="cuda").reshape(6, 8).contiguous()
     before = k.clone()
     comm.allgather_rows(k, 5)
@@ -155,3 +156,37 @@ def test_2d_block_cyclic_fit_on_the_gpu_matches_single_gpu(tmp_path, pr, pc, n, 
         assert np.linalg.norm(g["alpha"] - a0) / np.linalg.norm(a0) < 1e-7
         assert np.linalg.norm(g["mean"] - m0.ravel()) / np.linalg.norm(m0) < 1e-8
         np.testing.assert_allclose(g["var"], v0, rtol=1e-4)
+
+
+def _bench_line(argv, env_extra, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE line on stdout, whatever the ranks printed
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2` with NO launcher around it and no WORLD_SIZE in the environment -- the way the driver ran the
+    N = 1 record -- starts its ranks as a child torch.distributed.run, relays one parsable line and exits 0.  Two ranks share the
+    test box's one GPU (gloo); the line must say two ranks took part and carry the alpha of the one-rank run."""
+    import json
+    argv = ["--config", "cfg1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    two = _bench_line(["--gpus", "2"] + argv, {"NNGP_DIST_BACKEND": "gloo"})
+    one = _bench_line(["--gpus", "1"] + argv, {})
+    assert two["n_gpus"] == 2 and two["shard"]["ranks_seen"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["N"] == one["config"]["N"] == 1000
+    assert abs(two["fit_info"]["alpha_l2"] - one["fit_info"]["alpha_l2"]) <= 1e-9 * one["fit_info"]["alpha_l2"]
+    assert two["fit_info"]["clamped_pivots"] == 0 and two["fit_info"]["rel_residual"] < 1e-10
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r3_bench_selflaunch_2rank_gloo.json"), "w") as f:
+            json.dump({"two_ranks": two, "one_rank": one}, f, indent=1)
+    # without a device for every rank and without an explicit backend the child falls back to the rehearsal backend and says so
+    auto = _bench_line(["--gpus", "2", "--no-compare"] + argv, {})
+    assert auto["shard"]["ranks_seen"] == 2 and ("gloo" in auto["shard"]["collective"] or torch.cuda.device_count() >= 2)
