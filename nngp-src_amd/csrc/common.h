@@ -117,6 +117,9 @@ int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, floa
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
                       hipStream_t s, const float* row_alpha = nullptr);  // row_alpha: per-row factor of the product
+int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, const char* a2, const char* b2, int64_t ldp, int64_t m,
+                       int64_t n, int64_t k, int64_t k2, float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters,
+                       int reserve_cus, hipStream_t s, const float* row_alpha = nullptr);  // + a second panel pair (k2 > 0)
 
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
