@@ -117,9 +117,17 @@ int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, floa
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
                       hipStream_t s, const float* row_alpha = nullptr);  // row_alpha: per-row factor of the product
-int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, const char* a2, const char* b2, int64_t ldp, int64_t m,
-                       int64_t n, int64_t k, int64_t k2, float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters,
-                       int reserve_cus, hipStream_t s, const float* row_alpha = nullptr);  // + a second panel pair (k2 > 0)
+// up to four regions of C per launch, all with the same panels: C(row0 + i, col0 + j) for i < m, j < n (lower_only: j <= i + shift);
+// their A rows start row0 rows, their B rows col0 rows into the split rows at a / b
+struct H3RegionSpec {
+    int64_t row0, col0, m, n, shift;
+};
+int launch_gemm_nt_h3r(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
+                       const H3RegionSpec* spec, int nreg, int64_t k, float alpha, float beta, bool lower_only, int* counters,
+                       int reserve_cus, hipStream_t s, const float* row_alpha = nullptr);
+int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
+                       int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters,
+                       int reserve_cus, hipStream_t s, const float* row_alpha = nullptr);  // sum over npanels panels, one pass over C
 
 // ---- potrf.hip ----
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s);
@@ -161,16 +169,18 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
     hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};
     // live timing of the split-float16 trailing updates (nngp_model_update_timer): event pairs around each launch
+    static constexpr int kMaxTimed = 320;  // split-float16 update launches of one factorisation (grouped form: ~3 per block column)
     bool time_updates = false;
-    hipEvent_t tu0[kMaxSteps] = {}, tu1[kMaxSteps] = {};
+    hipEvent_t tu0[kMaxTimed] = {}, tu1[kMaxTimed] = {};
     int tu_count = 0;              // launches of the last factorisation
-    double tu_flops[kMaxSteps] = {};
+    double tu_flops[kMaxTimed] = {};
 };
 int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
                         LookAhead* la, SplitWork* sw, hipStream_t user);
 constexpr int64_t kLookAheadNb = 1024;  // block-column width of the look-ahead Cholesky
+constexpr int kLookAheadGroup = 4;      // block columns per deep-K far update (potrf.hip, grouped form)
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
                     int64_t w, hipStream_t s);
 int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s,

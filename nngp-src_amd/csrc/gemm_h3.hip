@@ -391,108 +391,187 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3(float* C, int64_t ldc, const
 // any issue of stage t.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool LOWER>
+// Tile boundaries (a workgroup's compute unit idles from its last MFMA of one tile to the first of the next): the work slot of the
+// NEXT tile is fetched during the last stage of the current one, the next tile's first operand stage is requested BEFORE the
+// current tile's epilogue, and the epilogue itself requests the old C values of three 32-row quarters at once, combines them in
+// place as they arrive and issues all 32 stores at the end -- no store sits between two loads in the in-order vmcnt queue, so no
+// wait for a load ever includes a store's acknowledgement, and the next main loop starts without waiting for the stores.
+struct H3Region {
+    int64_t c_off;  // elements from C to the region's origin
+    int64_t a_off;  // bytes from A to the split rows of the region's first row
+    int64_t b_off;  // bytes from B to the split rows of the region's first column
+    int m, n, shift, blk0;  // extent, diagonal shift (LOWER: col <= row + shift), first tile block in the launch's enumeration
+};
+struct H3Regions {
+    int count, nblk;
+    H3Region r[4];
+};
+
+#ifdef NNGP_TIMING_KNOBS
+// ABL = 256: cycles (s_memtime) of workgroup 0, waves 0 and 4, per tile segment, summed over its tiles:
+// [w][0] main loop, [1] slot + decode, [2] old C requested -> combined, [3] stores issued, [4] barrier + next stage 0 landed,
+// [5] tiles, [6] s_memtime over the kernel, [7] s_memrealtime (100 MHz) over the kernel
+__device__ unsigned long long g_h3_stamps[2 * 8];
+#endif
+// ABL (timing diagnostics, instantiated in libnngp_hip_knobs.so only; a run-time switch changed the code hipcc generates for the
+// epilogue): 1 no operand loads after the first stage, 2 no MFMA, 8 no C traffic, 16 no C loads, 32 no C stores.
+template <bool LOWER, int ABL>
 __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, const char* A, const char* B, int64_t ldp,
-                                                      const char* A2, const char* B2, int nk2, int m, int n, int tiles_m, int nk,
-                                                      float alpha, float beta, int diag_shift, int order_br, int order_bc,
-                                                      int* counters, int slots_per_xcd, int ablate, const float* row_alpha) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * HSTAGE + 16];  // ONE object (see k_gemm_nt_h3)
-    int& s_slot = *reinterpret_cast<int*>(smem + 2 * HSTAGE);
+                                                      int64_t pstride, int npanels, int nk_first, int first_off, H3Regions regs, int nk,
+                                                      float alpha, float beta, int order_br, int order_bc,
+                                                      int* counters, int slots_per_xcd, const float* row_alpha) {
+    constexpr int ablate = ABL;
+    // ONE object (see k_gemm_nt_h3), all 160 KB: two operand stages of 64 KB; in the epilogue 20 KB of C staging per wave.  The
+    // work-slot word is only touched between a tile's last fragment read and its epilogue, when nothing else lives in LDS.
+    __shared__ __attribute__((aligned(1024))) char smem[8 * 20480];
+    int& s_slot = *reinterpret_cast<int*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (n + HT - 1) / HT;
     const int xcd = blockIdx.x & 7;
     const int group = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int w4 = __builtin_amdgcn_readfirstlane(wave & 3);
     const int l3 = lane >> 3;
     const int r16 = lane & 15, q4 = lane >> 4;
-    // per-lane byte offset inside an 8-row piece (32-bit: the piece bases below are wave-uniform, so the loads take the
-    // scalar-base + lane-offset form and no 64-bit address lives in vector registers)
+    // per-lane byte offset inside an 8-row piece (32-bit: the piece bases below are wave-uniform)
     const unsigned lane_off = (unsigned)l3 * (unsigned)ldp + (((lane & 7) ^ ((4 * (w4 & 1) + (l3 >> 1)) & 7)) << 4);
     // fragment reads: row = 16-row block base + r16, so the swizzle term ((row >> 1) & 7) = (r16 >> 1) is a lane constant and
     // every fragment address is one lane offset + a compile-time constant (hi chunk q4, lo chunk 4 + q4 = hi ^ 64 bytes)
     const unsigned frag_hi = (unsigned)r16 * HROW + (((unsigned)q4 ^ ((unsigned)r16 >> 1)) << 4);
     const unsigned frag_lo = frag_hi ^ 64u;
-    const int nstage = nk + nk2;
+    // K runs over `npanels` panels of one row stride: panel p (p = 0 is the LATEST block column, processed first) lies pstride bytes
+    // below panel p - 1; every panel has nk k-blocks except the earliest (processed last): nk_first blocks starting first_off bytes
+    // into its rows.  Inside a panel the k-blocks are walked from the high end down (small terms first, see gemm_f32.hip).
+    const int nstage = (npanels - 1) * nk + nk_first;
 
-    for (;;) {
-        if (tid == 0) s_slot = atomicAdd(&counters[xcd], 1);
-        __syncthreads();
-        const int slot = __builtin_amdgcn_readfirstlane(s_slot);  // wave-uniform by construction: keep the tile indices scalar
-        __syncthreads();
-        if (slot >= slots_per_xcd) {
-            if (tid == 0 && atomicAdd(&counters[8], 1) == (int)gridDim.x - 1)
-                for (int i = 0; i < 9; ++i) __hip_atomic_store(&counters[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        int bi, bj;
-        {
-            const int per = order_br * order_bc;
-            int G = (slot / per) * 8 + xcd;
-            const int i = slot % per;
-            const int brows = (tiles_m + order_br - 1) / order_br;
-            const int sh_t = (diag_shift + HT - 1) / HT;
-            int gr = 0;
-            for (; gr < brows; ++gr) {
-                const int cnt = h3_block_cols(gr, order_br, order_bc, tiles_m, tiles_n, LOWER, sh_t);
-                if (G < cnt) break;
-                G -= cnt;
-            }
-            if (gr >= brows) continue;
-            bi = gr * order_br + (i % order_br);
-            bj = G * order_bc + (i / order_br);
-            if (bi >= tiles_m || bj >= tiles_n) continue;
-        }
-        if (LOWER && bj * HT > bi * HT + HT - 1 + diag_shift) continue;
-
-        // stage t reads k block nk-1-t of (A, B) for t < nk, then k block nk2-1-(t-nk) of (A2, B2): high k first
-        auto stage_base = [&](int t, const char*& pa, const char*& pb) {
-            if (t < nk) {
-                const int64_t ko = (int64_t)(nk - 1 - t) * 128;
-                pa = A + (int64_t)bi * HT * ldp + ko;
-                pb = B + (int64_t)bj * HT * ldp + ko;
-            } else {
-                const int64_t ko = (int64_t)(nk2 - 1 - (t - nk)) * 128;
-                pa = A2 + (int64_t)bi * HT * ldp + ko;
-                pb = B2 + (int64_t)bj * HT * ldp + ko;
-            }
-        };
-        auto glds_b = [&](int t) {  // the wave's 4 B pieces of stage t
-            const char *pa, *pb;
-            stage_base(t, pa, pb);
-            char* dst = smem + (t & 1) * HSTAGE + HT * HROW;
+    // slot -> tile (wave-uniform arithmetic); false: the slot holds no tile of this launch
+    // Work stealing: a workgroup pulls slots from its own XCD's counter (tiles whose panels its neighbours share through the L2)
+    // until that runs dry, then from the next XCD's, and so on round the ring -- a launch of a few tile blocks (27 blocks of a
+    // 4-tile-wide update over 8 XCDs: three get 64 tiles, five 48) otherwise ends when its fullest XCD does.
+    int vx = xcd, tries = 0;
+    // A launch covers up to four regions of C with the same panels (the pieces of one far update of the grouped Cholesky): the
+    // tile blocks of region r follow those of region r - 1 in the enumeration.
+    struct Tile {
+        const char* pa;  // split rows of the tile's 256 C rows, k block 0 of the latest panel
+        const char* pb;  // ... of its 256 C columns
+        float* pc;       // C(row0, col0) of the tile
+        int row0, col0;  // inside its region
+        int m, n, shift; // the region's extent and diagonal shift
+    };
+    auto decode = [&](int slot, Tile& tl) -> bool {
+        const int per = order_br * order_bc;
+        int G = (slot / per) * 8 + vx;
+        const int i = slot % per;
+        if (G >= regs.nblk) return false;
+        int ri = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int piece = group * 16 + e * 4 + w4;
-                __builtin_amdgcn_global_load_lds((glb_void*)(pb + (int64_t)piece * 8 * ldp + lane_off), (lds_void*)(dst + piece * 1024), 16, 0, 0);
-            }
-        };
-        auto glds_a = [&](int t) {  // the wave's 4 A pieces of stage t: rows 0-63 of its group first (e = 0, 1), then rows 64-127
-            const char *pa, *pb;
-            stage_base(t, pa, pb);
-            char* dst = smem + (t & 1) * HSTAGE;
+        for (int r = 1; r < 4; ++r)
+            if (r < regs.count && G >= regs.r[r].blk0) ri = r;
+        const int m = regs.r[ri].m, n = regs.r[ri].n, diag_shift = regs.r[ri].shift;
+        G -= regs.r[ri].blk0;
+        const int tiles_m = (m + HT - 1) / HT, tiles_n = (n + HT - 1) / HT;
+        const int brows = (tiles_m + order_br - 1) / order_br;
+        const int sh_t = (diag_shift + HT - 1) / HT;
+        int gr = 0;
+        for (; gr < brows; ++gr) {
+            const int cnt = h3_block_cols(gr, order_br, order_bc, tiles_m, tiles_n, LOWER, sh_t);
+            if (G < cnt) break;
+            G -= cnt;
+        }
+        if (gr >= brows) return false;
+        const int bi = gr * order_br + (i % order_br);
+        const int bj = G * order_bc + (i / order_br);
+        if (bi >= tiles_m || bj >= tiles_n) return false;
+        if (LOWER && bj * HT > bi * HT + HT - 1 + diag_shift) return false;
+        tl.pa = A + regs.r[ri].a_off + (int64_t)bi * HT * ldp;
+        tl.pb = B + regs.r[ri].b_off + (int64_t)bj * HT * ldp;
+        tl.pc = C + regs.r[ri].c_off + (int64_t)bi * HT * ldc + (int64_t)bj * HT;
+        tl.row0 = bi * HT;
+        tl.col0 = bj * HT;
+        tl.m = m;
+        tl.n = n;
+        tl.shift = diag_shift;
+        return true;
+    };
+    // load cursor: panel and k-block of the next stage to request (wave-uniform)
+    int cur_p = 0, cur_kb = 0;
+    auto cursor_reset = [&]() { cur_p = 0; cur_kb = (npanels == 1 ? nk_first : nk) - 1; };
+    auto cursor_take = [&]() -> int64_t {  // byte offset of the cursor's k-block from the tile's row base; advances the cursor
+        const int64_t off = (int64_t)cur_kb * 128 - (int64_t)cur_p * pstride + (cur_p == npanels - 1 ? first_off : 0);
+        if (--cur_kb < 0) {
+            ++cur_p;
+            cur_kb = (cur_p == npanels - 1 ? nk_first : nk) - 1;
+        }
+        return off;
+    };
+    auto glds_b = [&](int t, int64_t koff, const char* tile_pb) {  // the wave's 4 B pieces of stage t
+        const char* pb = tile_pb + koff;
+        char* dst = smem + (t & 1) * HSTAGE + HT * HROW;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int piece = group * 16 + e * 4 + w4;
-                __builtin_amdgcn_global_load_lds((glb_void*)(pa + (int64_t)piece * 8 * ldp + lane_off), (lds_void*)(dst + piece * 1024), 16, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            const int piece = group * 16 + e * 4 + w4;
+            __builtin_amdgcn_global_load_lds((glb_void*)(pb + (int64_t)piece * 8 * ldp + lane_off), (lds_void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto glds_a = [&](int t, int64_t koff, const char* tile_pa) {  // the wave's 4 A pieces of stage t: rows 0-63 of its group first (e = 0, 1), then rows 64-127
+        const char* pa = tile_pa + koff;
+        char* dst = smem + (t & 1) * HSTAGE;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int piece = group * 16 + e * 4 + w4;
+            __builtin_amdgcn_global_load_lds((glb_void*)(pa + (int64_t)piece * 8 * ldp + lane_off), (lds_void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    // next valid tile of this workgroup, fetched synchronously (first tile, and after a slot without a tile)
+    auto fetch_tile = [&](Tile& tl) -> bool {
+        for (;;) {
+            if (tid == 0) s_slot = atomicAdd(&counters[vx], 1);
+            __syncthreads();
+            const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+            __syncthreads();  // s_slot may be rewritten only after every wave has read it
+            if (slot >= slots_per_xcd) {
+                if (++tries >= 8) return false;
+                vx = (vx + 1) & 7;
+                continue;
             }
-        };
+            if (decode(slot, tl)) return true;
+        }
+    };
 
+#ifdef NNGP_TIMING_KNOBS
+    const bool stamping = (ablate & 256) && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+    unsigned long long st_last = 0, st_k0 = 0, st_r0 = 0;
+    if (stamping) { st_k0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define H3_STAMP(i) do { if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                         if ((i) >= 0) g_h3_stamps[(wave >> 2) * 8 + ((i) < 0 ? 0 : (i))] += now_ - st_last; st_last = now_; } } while (0)
+#else
+#define H3_STAMP(i) do { } while (0)
+#endif
+    Tile tl = {};
+    bool have = fetch_tile(tl);
+    if (have) {
+        cursor_reset();
+        const int64_t k0 = cursor_take();
+        glds_b(0, k0, tl.pb);
+        glds_a(0, k0, tl.pa);
+    }
+    while (have) {
         f32x4v acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
 
-        glds_b(0);
-        glds_a(0);
+        // stage 0 was requested before the previous tile's epilogue (or just above); every wave waits for its own pieces
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (group == 1) __builtin_amdgcn_s_barrier();  // stagger
+        H3_STAMP(st_last == 0 ? -1 : 4);
+        int next_slot = 0;
         for (int t = 0; t < nstage; ++t) {
             const char* sa_ = smem + (t & 1) * HSTAGE;
             const char* sb_ = sa_ + HT * HROW;
             const bool more = t + 1 < nstage && !(ablate & 1);
+            const int64_t knext = more ? cursor_take() : 0;
             h8 bh[4], bl[4], ah[4], al[4];
             // ---- phase A: wave rows 0-63 ----
 #pragma unroll
@@ -508,10 +587,14 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, con
                 al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
             }
             if (more) {
-                glds_b(t + 1);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                glds_b(t + 1, knext, tl.pb);
+                // retires the wave's last two A pieces of stage t (read in phase B).  Stage 0 has none outstanding, and a wait
+                // here would also cover the previous tile's stores, which are still on their way
+                if (t > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // last stage: take the next work slot now; its round trip runs under this stage's MFMAs (no counted wait follows)
+                if (tid == 0) next_slot = atomicAdd(&counters[vx], 1);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -547,8 +630,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, con
                 al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
             }
             if (more) {
-                glds_a(t + 1);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                glds_a(t + 1, knext, tl.pa);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires the B pieces issued in phase A
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -574,72 +657,100 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, con
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // retires the A pieces of rows 0-63 of stage t+1
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
         if (group == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
 
-        // epilogue: acc[i][j][r] = C[row_base + 16 i + (lane & 15)][col_base + 16 j + 4 (lane >> 4) + r]: one 16-byte access per
-        // accumulator, lane address = wave-uniform band base + one 32-bit lane offset.  A workgroup's compute unit idles while
-        // it waits for old C values, so the round trips are pipelined: the loads of two 32-row quarters (8 each) are kept in
-        // flight while a third quarter is combined and stored (the first form: four dependent round trips per tile).
-        // m, n are multiples of 128, so a 16 x 64 band of the wave's sub-tile is inside or outside as a whole; tiles that are
-        // entirely inside (all but the diagonal and edge tiles) take the branch-free path.
-        const int row_base = bi * HT + group * 128;
-        const int col_base = bj * HT + w4 * 64;
-        const unsigned voff = ((unsigned)r16 * (unsigned)ldc + 4u * (unsigned)q4) * 4u;  // bytes; ldc < 2^26 (checked by the launcher)
-        char* cw = reinterpret_cast<char*>(C + (int64_t)row_base * ldc + col_base);      // wave-uniform
+        H3_STAMP(0);
+        // ---- the next tile: slot (requested in the last stage), decode, first operand stage ----
+        const Tile ct = tl;  // the tile whose accumulators are in registers
+        if (tid == 0) s_slot = next_slot;
+        __syncthreads();
+        int slot = __builtin_amdgcn_readfirstlane(s_slot);
+        __syncthreads();
+        have = slot < slots_per_xcd && decode(slot, tl);
+        if (!have) {  // this counter ran dry (move on to the next XCD's), or a slot of the padded enumeration held no tile
+            if (slot >= slots_per_xcd) {
+                ++tries;
+                vx = (vx + 1) & 7;
+            }
+            have = tries < 8 && fetch_tile(tl);
+        }
+
+        H3_STAMP(1);
+        // ---- epilogue of tile (ci, cj): acc[i][j][r] = C[row_base + 16 i + (lane & 15)][col_base + 16 j + 4 (lane >> 4) + r], one
+        // 16-byte access per accumulator, lane address = wave-uniform band base + one 32-bit lane offset.  m, n are multiples of
+        // 128, so a 16 x 64 band of the wave's sub-tile is inside or outside as a whole; tiles entirely inside (all but the
+        // diagonal and edge tiles) take the branch-free path.
+        const int m = ct.m, n = ct.n, diag_shift = ct.shift;
+        const int row_base = ct.row0 + group * 128;  // inside the tile's region
+        const int col_base = ct.col0 + w4 * 64;
+        const unsigned voff = ((unsigned)r16 * (unsigned)ldc + 4u * (unsigned)q4) * 4u;  // bytes; 16 ldc < 2^30 (checked by the launcher)
+        char* cw = reinterpret_cast<char*>(ct.pc + (int64_t)(group * 128) * ldc + w4 * 64);  // wave-uniform
         const int64_t band = (int64_t)16 * ldc * 4;                                       // bytes between 16-row bands
-        const bool full = !(ablate & 8) && col_base + 64 <= n && row_base + 128 <= m &&
+        const bool full = !(ablate & 8) && beta != 0.0f && col_base + 64 <= n && row_base + 128 <= m &&
                           !(LOWER && (col_base >> 7) > ((row_base + diag_shift) >> 7));  // the first band's 128-block decides: later bands lie lower
-        if (full) {
+        if (full) {  // (beta == 0 -- the C-ABI tests only -- takes the band-by-band path: a second store-only branch here shared its
+                     // alpha * acc products with this one, hipcc hoisted all 128 of them above the branch and spilled)
+            // ALL old values are requested at once: a workgroup reads its C tile at the rate its requests in flight allow
+            // (measured: 14 us per tile with 96 KB in flight, two to three dependent round trips), and the registers hold only
+            // part of a sub-tile beside the accumulators -- so bands 3-7 come in by LDS-DMA into the wave's own 20 KB of the (now
+            // idle) LDS, bands 0-2 into registers; the LDS part is then read back band by band.
+            constexpr int RB = 3;  // bands through registers
+            char* stage_c = smem + (wave * 20480);
+            if (!(ablate & 16)) {
+#pragma unroll
+                for (int i = RB; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(cw + i * band + voff + 64 * j),
+                                                         (lds_void*)(stage_c + ((i - RB) * 4 + j) * 1024), 16, 0, (ablate & 64) ? 2 : 0);
+            }
+            f32x4v cold[RB][4];
             float ra[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) ra[i] = alpha * (row_alpha != nullptr ? row_alpha[row_base + 16 * i + r16] : 1.0f);
-            if (beta != 0.0f) {
-                f32x4v cold[3][2][4];  // three quarters in rotation (two in flight + the one being combined)
-                auto ld_q = [&](int q, int slot_) {
 #pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            cold[slot_][b2][j] = (ablate & 16) ? f32x4v{0.0f, 0.0f, 0.0f, 0.0f}
-                                                               : *reinterpret_cast<const f32x4v*>(cw + (2 * q + b2) * band + voff + 64 * j);
-                };
-                auto st_q = [&](int q, int slot_) {
+                for (int j = 0; j < 4; ++j)
+                    cold[i][j] = (ablate & 16) ? f32x4v{0.0f, 0.0f, 0.0f, 0.0f}
+                                                : (ablate & 64) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(cw + i * band + voff + 64 * j))
+                                                                : *reinterpret_cast<const f32x4v*>(cw + i * band + voff + 64 * j);
+            auto fma_b = [&](int i, int slot_) {
 #pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2)
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4v v = acc[2 * q + b2][j];
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(beta, cold[slot_][j][r], ra[i] * acc[i][j][r]);
+                    // pin: the combined values exist HERE (hipcc otherwise sinks the arithmetic down to the stores)
+                    asm volatile("" : "+v"(acc[i][j]) : : "memory");
+                }
+            };
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaf(beta, cold[slot_][b2][j][r], ra[2 * q + b2] * v[r]);
-                            if (ablate & 32)
-                                asm volatile("" ::"v"(v));
-                            else
-                                *reinterpret_cast<f32x4v*>(cw + (2 * q + b2) * band + voff + 64 * j) = v;
-                        }
-                };
-                ld_q(0, 0);
-                ld_q(1, 1);
-                st_q(0, 0);
-                ld_q(2, 2);
-                st_q(1, 1);
-                ld_q(3, 0);
-                st_q(2, 2);
-                st_q(3, 0);
-            } else {
+            for (int i = 0; i < RB; ++i) fma_b(i, i);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own LDS-DMA pieces (older than the register loads) have landed
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+            for (int i = RB; i < 8; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4v v = acc[i][j];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= ra[i];
-                        *reinterpret_cast<f32x4v*>(cw + i * band + voff + 64 * j) = v;
-                    }
+                for (int j = 0; j < 4; ++j)
+                    cold[(i - RB) % RB][j] = (ablate & 16) ? f32x4v{0.0f, 0.0f, 0.0f, 0.0f}
+                                                           : *reinterpret_cast<const f32x4v*>(stage_c + ((i - RB) * 4 + j) * 1024 + lane * 16);
+                fma_b(i, (i - RB) % RB);
             }
+            H3_STAMP(2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ablate & 32)
+                        asm volatile("" ::"v"(acc[i][j]));
+                    else if (ablate & 64)
+                        __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4v*>(cw + i * band + voff + 64 * j));
+                    else
+                        *reinterpret_cast<f32x4v*>(cw + i * band + voff + 64 * j) = acc[i][j];
+                }
         } else {
 #pragma unroll 1
             for (int i = 0; i < 8; ++i) {  // diagonal / edge tiles: band by band
@@ -672,7 +783,35 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, con
                 }
             }
         }
+        H3_STAMP(3);
+#ifdef NNGP_TIMING_KNOBS
+        if (stamping) g_h3_stamps[(wave >> 2) * 8 + 5] += 1;
+#endif
+        if (ablate & 8) {  // keep the products alive in the no-C-traffic diagnostic build
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        }
+        if (have) {  // the C staging areas overlap the operand stages: every wave's reads of them are retired first
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cursor_reset();
+            const int64_t k0 = cursor_take();
+            glds_b(0, k0, tl.pb);
+            glds_a(0, k0, tl.pa);
+        }
     }
+#ifdef NNGP_TIMING_KNOBS
+    if (stamping) {
+        g_h3_stamps[(wave >> 2) * 8 + 6] += __builtin_amdgcn_s_memtime() - st_k0;
+        g_h3_stamps[(wave >> 2) * 8 + 7] += __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
+#undef H3_STAMP
+    // The work counters reset themselves: the last workgroup to run out of work zeroes them for the next launch (see k_gemm_nt_h3)
+    if (tid == 0 && atomicAdd(&counters[8], 1) == (int)gridDim.x - 1)
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(&counters[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -717,35 +856,55 @@ int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, floa
 // a, b: split rows (row stride ldp bytes); rows of a / b up to the next multiple of 256 must be readable (their
 // products are never stored).  m, n multiples of 128; k a multiple of 32.  counters: 16 device ints owned by the caller,
 // zero before the first launch (the kernel leaves them zero again).  reserve_cus: compute units left free for other streams (the grid is one workgroup
-// per remaining unit).  a2, b2, k2 (optional): a second panel pair of the same row stride, accumulated after the first
-// (C = beta C + alpha (A B^T + A2 B2^T), k blocks of (a, b) from the high end down, then those of (a2, b2)).
+// per remaining unit).  Several panels per launch (launch_gemm_nt_h3x): C = beta C + alpha sum_p A_p B_p^T over `npanels` panels of
+// k columns each; a, b point at the LATEST panel (processed first) and panel p lies pstride bytes below panel p - 1 (the block
+// columns of SplitWork::planes); the earliest panel contributes its columns [lead, k) only.  One pass over C for the whole sum.
 constexpr int kH3DefaultForm = 2;  // 1: k_gemm_nt_h3 (32x32x16), 2: k_gemm_nt_h3v2 (16x16x32, balanced loads); debug key 5 = 40 + form
 
-int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, const char* a2, const char* b2, int64_t ldp, int64_t m,
-                       int64_t n, int64_t k, int64_t k2, float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters,
+int launch_gemm_nt_h3r(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
+                       const H3RegionSpec* spec, int nreg, int64_t k, float alpha, float beta, bool lower_only, int* counters,
                        int reserve_cus, hipStream_t s, const float* row_alpha) {
-    if (m <= 0 || n <= 0) return 0;
-    NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k > 0 && k % 32 == 0 && diag_shift % 128 == 0 && diag_shift >= 0,
-                 "gemm_nt_h3: m, n must be multiples of 128 and k of 32 (m=%lld n=%lld k=%lld)", (long long)m,
-                 (long long)n, (long long)k);
-    NNGP_REQUIRE(ldp >= 4 * k && ldp % 16 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ldc >= n &&
-                     counters != nullptr,
+    NNGP_REQUIRE(nreg >= 1 && nreg <= 4 && spec != nullptr, "gemm_nt_h3: 1 to 4 regions per launch");
+    NNGP_REQUIRE(k > 0 && k % 32 == 0, "gemm_nt_h3: k must be a multiple of 32 (k=%lld)", (long long)k);
+    NNGP_REQUIRE(ldp >= 4 * k && ldp % 16 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && counters != nullptr,
                  "gemm_nt_h3: operands must be 16-byte aligned");
-    NNGP_REQUIRE(k2 == 0 || (k2 > 0 && k2 % 32 == 0 && ldp >= 4 * k2 && a2 != nullptr && b2 != nullptr && ((uintptr_t)a2 & 15) == 0 &&
-                             ((uintptr_t)b2 & 15) == 0),
-                 "gemm_nt_h3: bad second panel");
-    const int64_t tm = (m + HT - 1) / HT, tn = (n + HT - 1) / HT;
-    NNGP_REQUIRE(m < 2147483647LL && n < 2147483647LL, "gemm_nt_h3: matrix too large");
+    NNGP_REQUIRE(npanels >= 1 && lead >= 0 && lead < k && lead % 32 == 0 && (npanels == 1 || (pstride > 0 && pstride % 16 == 0)) &&
+                     ldc < (1LL << 26),
+                 "gemm_nt_h3: bad panel layout");
     int form = (NNGP_KNOB(5) >= 41 && NNGP_KNOB(5) <= 42) ? NNGP_KNOB(5) - 40 : kH3DefaultForm;
-    if (k2 > 0 || (ldc % 4 == 0 && ((uintptr_t)c & 15) == 0 && form == 2)) form = (ldc % 4 == 0 && ((uintptr_t)c & 15) == 0) ? 2 : 0;
-    NNGP_REQUIRE(form != 0, "gemm_nt_h3: a two-panel product needs a 16-byte aligned C with ldc a multiple of 4");
+    const bool c16 = ldc % 4 == 0 && ((uintptr_t)c & 15) == 0;  // form 2 reads and writes C with 16-byte accesses
+    if (npanels > 1 || lead > 0 || nreg > 1) {
+        NNGP_REQUIRE(c16, "gemm_nt_h3: a multi-panel or multi-region product needs a 16-byte aligned C with ldc a multiple of 4");
+        form = 2;
+    } else if (!c16) {
+        form = 1;
+    }
     // tile-block shape (debug key 5 = 10 + variant for A/B timing); 4 x 4 measured best at N = 8k .. 32k
     static const int kOrders[][2] = {{4, 4}, {8, 4}, {4, 8}, {2, 8}, {8, 2}, {8, 8}, {2, 16}, {2, 4}};
     const int variant = (NNGP_KNOB(5) >= 10 && NNGP_KNOB(5) < 18) ? NNGP_KNOB(5) - 10 : 0;
     const int br = kOrders[variant][0], bc = kOrders[variant][1];
+    H3Regions regs = {};
     int64_t nblk = 0;
-    for (int64_t gr = 0; gr < (tm + br - 1) / br; ++gr)
-        nblk += h3_block_cols((int)gr, br, bc, (int)tm, (int)tn, lower_only, (int)((diag_shift + HT - 1) / HT));
+    for (int r = 0; r < nreg; ++r) {
+        const H3RegionSpec& sp = spec[r];
+        if (sp.m <= 0 || sp.n <= 0) continue;
+        NNGP_REQUIRE(sp.m % 128 == 0 && sp.n % 128 == 0 && sp.shift % 128 == 0 && sp.shift >= 0 && sp.row0 >= 0 && sp.col0 >= 0 &&
+                         sp.m < 2147483647LL && sp.n < 2147483647LL && sp.col0 + sp.n <= ldc && sp.col0 % 4 == 0,
+                     "gemm_nt_h3: m, n must be multiples of 128 (m=%lld n=%lld)", (long long)sp.m, (long long)sp.n);
+        H3Region& rg = regs.r[regs.count++];
+        rg.c_off = sp.row0 * ldc + sp.col0;
+        rg.a_off = sp.row0 * ldp;
+        rg.b_off = sp.col0 * ldp;
+        rg.m = (int)sp.m;
+        rg.n = (int)sp.n;
+        rg.shift = lower_only ? (int)sp.shift : 0;
+        rg.blk0 = (int)nblk;
+        const int64_t tm = (sp.m + HT - 1) / HT, tn = (sp.n + HT - 1) / HT;
+        for (int64_t gr = 0; gr < (tm + br - 1) / br; ++gr)
+            nblk += h3_block_cols((int)gr, br, bc, (int)tm, (int)tn, lower_only, (int)((rg.shift + HT - 1) / HT));
+    }
+    if (regs.count == 0) return 0;
+    regs.nblk = (int)nblk;
     const int64_t slots_per_xcd = ((nblk + 7) / 8) * br * bc;
     NNGP_REQUIRE(slots_per_xcd < 2147483647LL / 8, "gemm_nt_h3: too many tiles");
     static std::atomic<int> ncu_cached{0};  // compute units of the device (every MI355X of a node has the same count)
@@ -760,32 +919,76 @@ int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, cons
     if (grid > slots_per_xcd * 8) grid = slots_per_xcd * 8;
     grid = (grid / 8) * 8;  // the same number of workgroups on every XCD
     if (grid < 8) grid = 8;
-    const int ablate = NNGP_KNOB(0) & 59;  // 1 no loads, 2 no MFMA, 8 no C traffic; form 2 also: 16 no C loads, 32 no C stores
+    const int ablate = NNGP_KNOB(0) & 507;  // 1 no loads, 2 no MFMA, 8 no C traffic; form 2 also: 16 no C loads, 32 no C stores
     if (form == 2) {
+#define NNGP_H3V2_LAUNCH(LOW, ABL)                                                                                                  \
+    hipLaunchKernelGGL((k_gemm_nt_h3v2<LOW, ABL>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, pstride, npanels,          \
+                       (int)((k - lead) / 32), (int)(lead * 4), regs, (int)(k / 32), alpha, beta, br, bc, counters,                  \
+                       (int)slots_per_xcd, row_alpha)
+#ifdef NNGP_TIMING_KNOBS
+        if (lower_only) {
+            switch (ablate) {
+                case 1: NNGP_H3V2_LAUNCH(true, 1); break;
+                case 2: NNGP_H3V2_LAUNCH(true, 2); break;
+                case 8: NNGP_H3V2_LAUNCH(true, 8); break;
+                case 9: NNGP_H3V2_LAUNCH(true, 9); break;
+                case 16: NNGP_H3V2_LAUNCH(true, 16); break;
+                case 32: NNGP_H3V2_LAUNCH(true, 32); break;
+                case 64: NNGP_H3V2_LAUNCH(true, 64); break;
+                case 256: NNGP_H3V2_LAUNCH(true, 256); break;
+                default: NNGP_H3V2_LAUNCH(true, 0); break;
+            }
+        } else
+#else
+        (void)ablate;
         if (lower_only)
-            hipLaunchKernelGGL((k_gemm_nt_h3v2<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, a2, b2, (int)(k2 / 32),
-                               (int)m, (int)n, (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters,
-                               (int)slots_per_xcd, ablate, row_alpha);
+            NNGP_H3V2_LAUNCH(true, 0);
         else
-            hipLaunchKernelGGL((k_gemm_nt_h3v2<false>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, a2, b2, (int)(k2 / 32),
-                               (int)m, (int)n, (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, ablate,
+#endif
+            NNGP_H3V2_LAUNCH(false, 0);
+#undef NNGP_H3V2_LAUNCH
+    } else {
+        // the first form: one region, one panel (kept for A/B timing and for a C that is not 16-byte aligned)
+        const H3Region& rg = regs.r[0];
+        const int64_t tm = (rg.m + HT - 1) / HT;
+        if (lower_only)
+            hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c + rg.c_off, ldc, a + rg.a_off, b + rg.b_off, ldp,
+                               rg.m, rg.n, (int)tm, (int)(k / 32), alpha, beta, rg.shift, br, bc, counters, (int)slots_per_xcd, ablate & 11,
                                row_alpha);
-    } else if (lower_only)
-        hipLaunchKernelGGL((k_gemm_nt_h3<true>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
-                           (int)tm, (int)(k / 32), alpha, beta, (int)diag_shift, br, bc, counters, (int)slots_per_xcd,
-                           ablate, row_alpha);
-    else
-        hipLaunchKernelGGL((k_gemm_nt_h3<false>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, (int)m, (int)n,
-                           (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, ablate, row_alpha);
+        else
+            hipLaunchKernelGGL((k_gemm_nt_h3<false>), dim3((unsigned)grid), dim3(512), 0, s, c + rg.c_off, ldc, a + rg.a_off, b + rg.b_off, ldp,
+                               rg.m, rg.n, (int)tm, (int)(k / 32), alpha, beta, 0, br, bc, counters, (int)slots_per_xcd, ablate & 11, row_alpha);
+    }
     NNGP_HIP_CHECK(hipGetLastError());
+#ifdef NNGP_TIMING_KNOBS
+    if (ablate == 256 && form == 2 && lower_only) {  // timing study: segments of workgroup 0, cumulative over the launches so far
+        unsigned long long h[16];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_h3_stamps), sizeof(h)) == hipSuccess)
+            for (int w = 0; w < 2; ++w)
+                fprintf(stderr, "h3v2 stamps m=%d wave %d: tiles %llu  main %llu  slot %llu  c_in %llu  stores %llu  next0 %llu  | kernel cycles %llu  "
+                                "realtime ticks %llu (clock %.3f GHz)\n", regs.r[0].m, 4 * w, h[w * 8 + 5], h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2],
+                        h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 6], h[w * 8 + 7], h[w * 8 + 7] ? 0.1 * (double)h[w * 8 + 6] / (double)h[w * 8 + 7] : 0.0);
+    }
+#endif
     return 0;
+}
+
+int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
+                       int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters,
+                       int reserve_cus, hipStream_t s, const float* row_alpha) {
+    if (m <= 0 || n <= 0) return 0;
+    NNGP_REQUIRE(ldc >= n && diag_shift % 128 == 0 && diag_shift >= 0, "gemm_nt_h3: bad ldc / diag_shift");
+    const H3RegionSpec one = {0, 0, m, n, diag_shift};
+    return launch_gemm_nt_h3r(c, ldc, a, b, ldp, pstride, npanels, lead, &one, 1, k, alpha, beta, lower_only, counters, reserve_cus, s,
+                              row_alpha);
 }
 
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
                       float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters, int reserve_cus,
                       hipStream_t s, const float* row_alpha) {
-    return launch_gemm_nt_h3x(c, ldc, a, b, nullptr, nullptr, ldp, m, n, k, 0, alpha, beta, lower_only, diag_shift, counters,
-                              reserve_cus, s, row_alpha);
+    return launch_gemm_nt_h3x(c, ldc, a, b, ldp, 0, 1, 0, m, n, k, alpha, beta, lower_only, diag_shift, counters, reserve_cus, s,
+                              row_alpha);
 }
 
 }  // namespace nngp

@@ -636,11 +636,231 @@ void lookahead_destroy(LookAhead* la) {
     (void)hipStreamDestroy(la->update);
     (void)hipEventDestroy(la->ev_in); (void)hipEventDestroy(la->ev_panel_done); (void)hipEventDestroy(la->ev_update_done);
     for (int i = 0; i < LookAhead::kMaxSteps; ++i) { (void)hipEventDestroy(la->ev_panel[i]); (void)hipEventDestroy(la->ev_col[i]); }
-    for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
+    for (int i = 0; i < LookAhead::kMaxTimed; ++i) {
         if (la->tu0[i]) (void)hipEventDestroy(la->tu0[i]);
         if (la->tu1[i]) (void)hipEventDestroy(la->tu1[i]);
     }
     delete la;
+}
+
+// ---- grouped form (round 3): deep-K trailing updates -----------------------------------------------------------------------
+// A 256 x 256 tile of the trailing update costs its workgroup ~60k cycles of C traffic and tile hand-over beside ~112k cycles
+// of matrix work per 1024 columns of K (in-kernel stamps, profiles/r3_h3_stamps.txt) -- a compute unit reads and writes its
+// 512 KB of C at ~25 GB/s while its matrix pipe idles, and with one workgroup per unit nothing else runs there meanwhile.
+// So K is deepened instead: the block columns are taken in groups of D.  A finished block column k is applied at once only
+// to the remaining columns of ITS group (a narrow update, K = 1024); the columns beyond the group receive the whole group in
+// ONE pass over C (K = 1024 D: measured 459 TF/s at K = 4096 against 360 at K = 1024).  The far update of a group is issued in
+// pieces, in stream order between the next group's panel steps, so that every diagonal-block factorisation on the panel
+// stream still runs under a large update:
+//   F0        next diagonal block (float32 GEMM, K = 1024 D)                    -> releases the panel stream
+//   chunk i   (while diagonal block gend + i is factored)  column gend + i + 1 of the next group (i = 0: also the rows of column
+//             gend below its diagonal block) and the i-th share of the columns beyond the next group
+// Every C tile is read and written 1 + (columns of its group before it) times per group pass instead of once per block column.
+struct FarWork {
+    bool active = false;
+    int g0 = 0, np = 0;        // first block column of the group, number of panels
+    int64_t r0 = 0;            // global row / column where the far region starts (= first row below the group)
+    int next = 0;              // next chunk to issue
+    int nchunks = 0;
+    int64_t share_lo[LookAhead::kMaxSteps + 1] = {};  // far-far shares: global column ranges [share_lo[i], share_lo[i + 1])
+};
+
+static int h3_update_timed(LookAhead* la, float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int np,
+                           int64_t lead, int64_t m, int64_t n, int64_t k, float alpha, bool lower, int64_t diag_shift, SplitWork* sw,
+                           int reserve, double entries) {
+    if (m <= 0 || n <= 0) return 0;
+    const bool timed = la->time_updates && la->tu_count < LookAhead::kMaxTimed;
+    if (timed) {
+        const int t = la->tu_count;
+        if (la->tu0[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu0[t]));
+        if (la->tu1[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu1[t]));
+        NNGP_HIP_CHECK(hipEventRecord(la->tu0[t], la->update));
+    }
+    NNGP_TRY(launch_gemm_nt_h3x(c, ldc, a, b, ldp, pstride, np, lead, m, n, k, alpha, 1.0f, lower, diag_shift, sw->counters, reserve,
+                                la->update));
+    if (timed) {
+        const int t = la->tu_count++;
+        NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
+        la->tu_flops[t] = 2.0 * entries * ((double)np * (double)k - (double)lead);
+    }
+    return 0;
+}
+
+// entries of the region rows [0, m) x cols [0, n) with col <= row + shift
+static double trap_entries(int64_t m, int64_t n, int64_t shift) {
+    double e = 0.0;
+    // rows r < n - shift see r + shift + 1 columns, the others n
+    const int64_t full_from = (n - shift - 1 > 0) ? n - shift - 1 : 0;  // first row that sees all n columns
+    const int64_t rt = full_from < m ? full_from : m;
+    e += (double)rt * (double)(shift + 1) + 0.5 * (double)rt * (double)(rt - 1);
+    if (m > rt) e += (double)(m - rt) * (double)n;
+    return e;
+}
+
+// float32-MFMA update of the lower trapezoid rows [0, m) x cols [0, n), n <= m (lower triangle inside the top n x n square):
+// c -= pa pb^T over K columns; pa, pb: rows of the factor (row stride ld), pb = the rows of the trapezoid's columns
+static int f32_update_trap(float* c, int64_t ld, const float* pa, const float* pb, int64_t m, int64_t n, int64_t kk, hipStream_t s) {
+    if (m <= 0 || n <= 0 || kk <= 0) return 0;
+    NNGP_TRY(launch_gemm_nt_f32(c, ld, pa, ld, pb, ld, n, n, kk, -1.0f, 1.0f, true, s));
+    if (m > n) NNGP_TRY(launch_gemm_nt_f32(c + n * ld, ld, pa + n * ld, ld, pb, ld, m - n, n, kk, -1.0f, 1.0f, false, s));
+    return 0;
+}
+
+static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, LookAhead* la,
+                                   SplitWork* sw, hipStream_t user, int64_t nb, int D) {
+    la->tu_count = 0;
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_in, 0));
+    const int nblk = (int)((n + nb - 1) / nb);
+    const int64_t ldp = 4 * sw->k_cap;
+    const float ascale = -1.0f / (sw->scale * sw->scale);
+    const int reserve = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
+    const int64_t lead0 = 64;  // columns of block column 0 that stay on the float32 MFMA (see potrf_lookahead_f32)
+    auto plane_rows = [&](int col, int64_t row) { return sw->planes + (int64_t)col * sw->col_stride + row * ldp; };
+    auto width = [&](int64_t col0) { return (n - col0 < nb) ? n - col0 : nb; };
+    FarWork far;
+
+    // One launch per chunk: up to three regions of the pending group's far update -- rows [row0, n) x cols [col0, col0 + w), lower
+    // trapezoid (col <= row + shift relative to the region's origin) -- with all panels of the group in one pass over C; the
+    // group's lead columns go through the float32 GEMM region by region.
+    auto far_chunk = [&]() -> int {
+        if (!far.active || far.next >= far.nchunks) return 0;
+        const int i = far.next++;
+        const int64_t r0 = far.r0;
+        H3RegionSpec reg[4];
+        int nreg = 0;
+        auto add = [&](int64_t row0, int64_t col0, int64_t w, int64_t shift) {
+            if (n - row0 > 0 && w > 0) reg[nreg++] = H3RegionSpec{row0, col0, n - row0, w, shift};
+        };
+        if (i == 0) {  // rows of the first column below its diagonal block (the block itself was F0)
+            const int64_t w0 = width(r0);
+            add(r0 + w0, r0, w0, w0);
+        }
+        const int64_t c1 = r0 + (int64_t)(i + 1) * nb;  // column gend + i + 1, if it belongs to the next group
+        if (c1 < n && i + 1 < D) add(c1, c1, width(c1), 0);
+        if (far.share_lo[i + 1] > far.share_lo[i]) add(far.share_lo[i], far.share_lo[i], far.share_lo[i + 1] - far.share_lo[i], 0);
+        if (far.next >= far.nchunks) far.active = false;
+        if (nreg == 0) return 0;
+        const int kl = far.g0 + far.np - 1;  // latest panel
+        const int64_t lead = far.g0 == 0 ? lead0 : 0;
+        double entries = 0.0;
+        for (int r = 0; r < nreg; ++r) entries += trap_entries(reg[r].m, reg[r].n, reg[r].shift);
+        const bool timed = la->time_updates && la->tu_count < LookAhead::kMaxTimed;
+        if (timed) {
+            const int t = la->tu_count;
+            if (la->tu0[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu0[t]));
+            if (la->tu1[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu1[t]));
+            NNGP_HIP_CHECK(hipEventRecord(la->tu0[t], la->update));
+        }
+        NNGP_TRY(launch_gemm_nt_h3r(a, ld, plane_rows(kl, 0), plane_rows(kl, 0), ldp, sw->col_stride, far.np, lead, reg, nreg, nb, ascale, 1.0f,
+                                    true, sw->counters, reserve, la->update));
+        if (timed) {
+            const int t = la->tu_count++;
+            NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
+            la->tu_flops[t] = 2.0 * entries * ((double)far.np * (double)nb - (double)lead);
+        }
+        if (lead > 0) {  // columns [0, lead) of block column 0
+            for (int r = 0; r < nreg; ++r) {
+                float* cr = a + reg[r].row0 * ld + reg[r].col0;
+                const float* pa = a + reg[r].row0 * ld;
+                const float* pb = a + reg[r].col0 * ld;
+                if (reg[r].shift == 0) {
+                    NNGP_TRY(f32_update_trap(cr, ld, pa, pb, reg[r].m, reg[r].n, lead, la->update));
+                } else {  // rows start `shift` below the columns: every entry of the columns is in
+                    NNGP_TRY(launch_gemm_nt_f32(cr, ld, pa, ld, pb, ld, reg[r].m, reg[r].n, lead, -1.0f, 1.0f, false, la->update));
+                }
+            }
+        }
+        return 0;
+    };
+
+    int rc = 0;
+    for (int k = 0; k < nblk && rc == 0; ++k) {
+        const int64_t o = (int64_t)k * nb;
+        const int64_t nbk = width(o);
+        const int64_t m = n - o - nbk;  // rows below this block column
+        float* akk = a + o * ld + o;
+        float* dk = dinv + (o / TB) * TB * TB;
+        const int g0 = (k / D) * D;
+        const int gend = (g0 + D < nblk) ? g0 + D : nblk;
+        // panel stream: factor the diagonal block (chain of small kernels)
+        if (k > 0) NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_col[k - 1], 0));
+        rc = potrf_rec(akk, nbk, ld, dk, clamped, pivot_floor, la->panel);
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_panel[k], la->panel));
+        if (rc != 0) break;
+        // update stream, while that factorisation runs: the next piece of the previous group's far update
+        rc = far_chunk();
+        if (rc != 0 || m == 0) break;
+        NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_panel[k], 0));
+        // solve all rows below in one fused launch; it leaves their float16 split copy in this block column's planes
+        const int64_t nb2 = width(o + nbk);
+        float* below = akk + nbk * ld;           // panel rows below the diagonal block: [m, nbk]
+        float* c = below + nbk;                  // trailing matrix: [m, m]
+        char* pk_rows = plane_rows(k, o + nbk);
+        if (k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr) {
+            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, la->update);
+            if (rc == 0) rc = launch_trsm_panel_h3(below, ld, m, sw->ldiag, sw->dfrag, nbk, pk_rows, ldp, sw->scale, la->update);
+        } else {
+            rc = launch_trsm_panel_f32(below, ld, m, akk, ld, dk, nbk, pk_rows, ldp, sw->scale, la->update);
+        }
+        if (rc != 0) break;
+        if (k + 1 < gend) {
+            // ---- inside the group: block column k goes to the group's remaining columns only (K = nbk) ----
+            rc = launch_gemm_nt_f32(c, ld, below, ld, below, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, la->update);  // next diagonal block
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_col[k], la->update));
+            int64_t wn = (int64_t)(gend - 1 - k) * nb;  // columns of the group after block column k
+            if (wn > m) wn = m;
+            const int64_t lead = (k == 0) ? lead0 : 0;
+            if (rc == 0 && m > nb2)
+                rc = h3_update_timed(la, c + nb2 * ld, ld, pk_rows + nb2 * ldp + lead * 4, pk_rows + lead * 4, ldp, 0, 1, 0, m - nb2, wn, nbk - lead,
+                                     ascale, true, nb2, sw, reserve, trap_entries(m - nb2, wn, nb2));
+            if (rc == 0 && lead > 0 && m > nb2) {
+                rc = launch_gemm_nt_f32(c + nb2 * ld, ld, below + nb2 * ld, ld, below, ld, m - nb2, nb2, lead, -1.0f, 1.0f, false, la->update);
+                if (rc == 0 && wn > nb2)
+                    rc = f32_update_trap(c + nb2 * ld + nb2, ld, below + nb2 * ld, below + nb2 * ld, m - nb2, wn - nb2, lead, la->update);
+            }
+        } else {
+            // ---- the group is complete: its far update starts with the next diagonal block (all panels, float32 GEMM) ----
+            const int np = k + 1 - g0;
+            const float* rows = a + (o + nbk) * ld + (int64_t)g0 * nb;  // rows below the group, columns of the group
+            rc = launch_gemm_nt_f32(c, ld, rows, ld, rows, ld, nb2, nb2, (int64_t)np * nb, -1.0f, 1.0f, true, la->update);
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_col[k], la->update));
+            far = FarWork();
+            far.active = true;
+            far.g0 = g0;
+            far.np = np;
+            far.r0 = o + nbk;
+            const int dn = (nblk - (k + 1) < D) ? nblk - (k + 1) : D;  // block columns of the next group
+            far.nchunks = dn;
+            // shares of the columns beyond the next group: equal trapezoid areas, whole block columns; few, large launches
+            const int64_t f0 = far.r0 + (int64_t)dn * nb;
+            for (int i = 0; i <= dn; ++i) far.share_lo[i] = f0 < n ? f0 : n;
+            if (f0 < n) {
+                const int64_t mf = n - f0;
+                const double total = 0.5 * (double)mf * (double)mf;
+                const double tiles = total / (256.0 * 256.0);
+                int ns = (int)(tiles / 700.0);  // >= ~3 tiles per compute unit and launch
+                if (ns < 1) ns = 1;
+                if (ns > dn) ns = dn;
+                double acc_area = 0.0;
+                int sidx = 1;
+                for (int64_t col = f0; col < n; col += nb) {
+                    const int64_t w = width(col);
+                    acc_area += (double)(n - col) * (double)w - 0.5 * (double)w * (double)w;
+                    if (sidx < ns && acc_area >= total * sidx / ns) far.share_lo[sidx++] = col + w;
+                }
+                for (int i = sidx; i <= dn; ++i) far.share_lo[i] = n;
+            }
+        }
+    }
+    while (rc == 0 && far.active) rc = far_chunk();  // (nothing is left when the loop ran to the last block column)
+    if (rc == 0) sw->l_ready = true;
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, la->panel));
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, la->update));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_panel_done, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_update_done, 0));
+    return rc;
 }
 
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
@@ -661,6 +881,10 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     // 58.9 ms, and 58.1 vs 57.9 ms with CUs reserved for the panel stream -- and solving the panel rows with that inverse as one GEMM: Cholesky -3.7 ms but CG iterations 6 -> 8)
     if (la == nullptr || NNGP_KNOB(2) == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
+    // grouped form: deep-K far updates (debug key 2 = 10 + D overrides the group size; D = 1: the round-2 form below)
+    const int group = (NNGP_KNOB(2) >= 11 && NNGP_KNOB(2) <= 26) ? NNGP_KNOB(2) - 10 : kLookAheadGroup;
+    if (h3 && group > 1 && nb == 1024 && (NNGP_KNOB(2) == 0 || NNGP_KNOB(2) >= 11) && NNGP_KNOB(3) == 0 && ld % 4 == 0)
+        return potrf_lookahead_grouped(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
     la->tu_count = 0;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));
@@ -765,7 +989,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                 // solves of the posterior read it again)
                 char* planes = pk_rows;
                 if (rc == 0 && !panel_split_done) rc = launch_split_rows(p, ld, m, nbk, sw->scale, planes, ldp, la->update);
-                const bool timed = la->time_updates && rc == 0 && la->tu_count < LookAhead::kMaxSteps;
+                const bool timed = la->time_updates && rc == 0 && la->tu_count < LookAhead::kMaxTimed;
                 if (timed) {  // events are created on first use (timing stream: the one the kernel is launched on)
                     const int t = la->tu_count;
                     if (la->tu0[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu0[t]));

@@ -87,6 +87,9 @@ def check():
 def time_plan():
     cfgs = os.environ.get("H3_CONFIGS", "5=41;5=42").split(";")
     shapes = [(30720, 30720, 1024, True), (16384, 16384, 1024, True), (1024, 31744, 1024, False)]
+    if os.environ.get("H3_SHAPES"):  # "m,n,k,lower;..."
+        shapes = [tuple(int(v) for v in sh.split(",")) for sh in os.environ["H3_SHAPES"].split(";")]
+        shapes = [(m, n, k, bool(lo)) for (m, n, k, lo) in shapes]
     rounds = int(os.environ.get("H3_ROUNDS", "5"))
     plan = []
     for (m, n, k, lower) in shapes:
