@@ -739,7 +739,9 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
         }
         const int64_t c1 = r0 + (int64_t)(i + 1) * nb;  // column gend + i + 1, if it belongs to the next group
         if (c1 < n && i + 1 < D) add(c1, c1, width(c1), 0);
-        if (far.share_lo[i + 1] > far.share_lo[i]) add(far.share_lo[i], far.share_lo[i], far.share_lo[i + 1] - far.share_lo[i], 0);
+        // shares are dealt from the LAST chunk backwards: the early chunks already carry the next group's own columns
+        const int si = far.nchunks - 1 - i;
+        if (far.share_lo[si + 1] > far.share_lo[si]) add(far.share_lo[si], far.share_lo[si], far.share_lo[si + 1] - far.share_lo[si], 0);
         if (far.next >= far.nchunks) far.active = false;
         if (nreg == 0) return 0;
         const int kl = far.g0 + far.np - 1;  // latest panel

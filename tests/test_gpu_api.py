@@ -316,11 +316,12 @@ def test_checkpoint_save_and_resume(tmp_path):
 
 
 def test_update_timer_reports_the_trailing_update_launches():
-    """bench.py's `roofline` is measured live: nngp_model_update_timer puts HIP events around every split-float16 trailing
-    update of the factorisation.  N = 5120 = 5 block columns: columns 0..2 have a trailing matrix beyond the next diagonal
-    block (m = 4096, 3072, 2048 > 1024), so three launches; their algorithmic work is 2 x (entries on or below the diagonal
-    in rows >= 1024 of the m x m trailing matrix) x (panel width; the first panel keeps 64 lead columns on the float32 MFMA).
-    The numbers must not change the fit."""
+    """bench.py's `roofline` is measured live: nngp_model_update_timer puts HIP events around every split-float16 update launch
+    of the factorisation.  N = 5120 = 5 block columns, grouped form with 4 columns per group (potrf.hip): block columns 0..2 are
+    applied to the rest of their group at once -- rows below the next diagonal block x the group's remaining columns, on or below
+    the diagonal (the diagonal blocks themselves are float32 GEMMs) -- so three launches; the group's far update has only the
+    last diagonal block to reach, which is a float32 GEMM too.  Their algorithmic work is 2 x entries x (panel width; the first
+    panel keeps 64 lead columns on the float32 MFMA).  The numbers must not change the fit."""
     n, d = 5120, 16
     x, y = synth.synthetic_queries(n, d, seed=21)
     model = GPModel(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3)
@@ -330,10 +331,15 @@ def test_update_timer_reports_the_trailing_update_launches():
     model.fit(x, y)
     launches, ms, flops = model.update_timer_read()
     assert launches == 3 and ms > 0.0
+
+    def entries(rows, cols, shift):  # (i, j), i < rows, j < cols, j <= i + shift
+        return sum(min(cols, i + shift + 1) for i in range(rows))
+
     want = 0.0
-    for k, m in enumerate((4096, 3072, 2048)):
-        width = 1024 - (64 if k == 0 else 0)
-        want += 2.0 * 0.5 * (m * (m + 1) - 1024 * 1025) * width
+    for k in range(3):
+        m = n - 1024 * (k + 1)                  # rows below block column k
+        wn = min(m, 1024 * (3 - k))             # columns of group 0 after block column k
+        want += 2.0 * entries(m - 1024, wn, 1024) * (1024 - (64 if k == 0 else 0))
     assert flops == pytest.approx(want, rel=1e-12)
     np.testing.assert_array_equal(model.alpha().cpu().numpy(), a0)
     model.update_timer(False)
