@@ -259,6 +259,16 @@ int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
  * triangle only: the product of the alpha CG (half the bytes of a plain GEMV, fixed summation order).  Any n >= 1; what
  * lies beyond row / column n in a padded buffer is never read. */
 int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream);
+/* Pool scoring of the active-learning loop on the device (reference: active/ActiveLearner.py:43-55, active_test):
+ * score_i = sqrt(max(var_i, 0)) / max_j mean[j * ny] (np.max(pred_mean, 0) of the single output column).
+ *   biased = 0: the `count` largest scores in ascending order of score -- np.argsort(score)[-count:];
+ *   biased = 1: `count` indices drawn without replacement with probability proportional to the score (the reference's
+ *               random.choice(..., replace=False, p=score / sum(score))), as a Gumbel top-k on the counter-based generator
+ *               u_i = splitmix64(seed, i) >> 11: the same draw on every device and in the host build, in draw order.
+ * mean [m, ny], var [m], indices [count] are device pointers (host pointers in the host build): only `count` indices have to
+ * travel to the host.  count <= m. */
+int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased,
+                     uint64_t seed, int64_t* indices, void* stream);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,
                       int64_t n, void* stream);

@@ -58,6 +58,7 @@ class ActiveLearner(object):
                 return self._model.predict(x_test, cov="diag" if compute_cov == "diag" else "full")
             return self._model.predict(x_test, cov=False)
 
+        predict_fn.model = self._model  # active_test scores the pool on the device through it
         return predict_fn
 
     # -- reference: ActiveLearner.test (ActiveLearner.py:33-40) --
@@ -71,6 +72,11 @@ class ActiveLearner(object):
 
     # -- reference: ActiveLearner.active_test (ActiveLearner.py:43-55) --
     def active_test(self, predict_fn, X_test, kernel_type="nngp"):
+        num_test = X_test.shape[0]
+        model = getattr(predict_fn, "model", None)
+        if model is not None and num_test > 0:
+            # std / max(mean), top-`budget` or the std-proportional draw, all on the GPU: only the indices come back
+            return model.select_pool(X_test, self.budget if num_test > self.budget else num_test, biased=self.biased_sample, seed=10)
         pred_mean, pred_var = predict_fn(x_test=X_test, get=kernel_type, compute_cov="diag")
         pred_std = np.sqrt(np.maximum(pred_var, 0.0))
         pred_std = pred_std / np.max(pred_mean, 0)

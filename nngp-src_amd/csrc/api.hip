@@ -1358,6 +1358,19 @@ int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
     return launch_gemm_nt_f64(c, ldc, cin, ldcin, a, lda, b, ldb, m, n, k, alpha, beta, (hipStream_t)stream);
 }
 
+int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased, uint64_t seed,
+                     int64_t* indices, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(mean != nullptr && var != nullptr && indices != nullptr && m > 0 && ny >= 1 && count >= 0 && count <= m,
+                 "pool_select: bad arguments (m=%lld, count=%lld)", (long long)m, (long long)count);
+    if (count == 0) return 0;
+    double* key = nullptr;
+    NNGP_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&key), sizeof(double) * (size_t)m, s));
+    const int rc = launch_pool_select(mean, m, ny, var, count, biased != 0, seed, key, indices, s);
+    NNGP_HIP_CHECK(hipFreeAsync(key, s));
+    return rc;
+}
+
 int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(a != nullptr && x != nullptr && y != nullptr && n > 0 && lda >= n, "symv_f64: bad arguments");

@@ -294,6 +294,8 @@ int launch_rows_alpha(const double* p, const double* q, int64_t ld, int64_t rows
 int launch_rows_axpy2(double* z, double* r, const double* p, const double* q, int64_t ld, int64_t rows, int64_t cols,
                       RowsPcg& w, hipStream_t s);
 
+int launch_pool_select(const double* mean, int64_t m, int ny, const double* var, int64_t count, int biased, uint64_t seed,
+                       double* key_ws, int64_t* indices, hipStream_t s);
 int launch_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t n, hipStream_t s);
 int launch_strided_copy_f64(const double* src, int64_t incs, double* dst, int64_t incd, int64_t n, hipStream_t s);
 

@@ -650,4 +650,66 @@ int launch_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd,
     return 0;
 }
 
+
+// ---- pool scoring of the active-learning loop (include/nngp_hip.h: nngp_pool_select; reference ActiveLearner.py:43-55) ----
+namespace {
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t seed, uint64_t idx) {  // nngp-src_amd/synth.py: splitmix64
+    uint64_t z = (idx + 1ULL) * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// key_i = score_i (top-k) or log(score_i) + Gumbel(u_i) (score-proportional draw without replacement); one workgroup
+__global__ __launch_bounds__(1024) void k_pool_keys(const double* __restrict__ mean, int64_t m, int ny, const double* __restrict__ var,
+                                                    int biased, uint64_t seed, double* __restrict__ key) {
+    __shared__ double red[16];
+    double mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) mx = fmax(mx, mean[i * ny]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < 16; ++w) mx = fmax(mx, red[w]);
+    for (int64_t i = threadIdx.x; i < m; i += 1024) {
+        const double sc = sqrt(fmax(var[i], 0.0)) / mx;
+        double k = sc;
+        if (biased) {
+            double u = (double)(splitmix64_dev(seed, (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
+            if (u < 1.1102230246251565e-16) u = 1.1102230246251565e-16;
+            k = (sc > 0.0) ? log(sc) - log(-log(u)) : -INFINITY;
+        }
+        key[i] = (k == k) ? k : -INFINITY;  // NaN never wins
+    }
+}
+
+// rank by counting: r_i = #{j : key_j > key_i, or key_j == key_i and j > i}; the `count` best go out
+__global__ __launch_bounds__(256) void k_pool_rank(const double* __restrict__ key, int64_t m, int64_t count, int biased,
+                                                   int64_t* __restrict__ out) {
+    __shared__ double tile[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double ki = (i < m) ? key[i] : 0.0;
+    int64_t r = 0;
+    for (int64_t j0 = 0; j0 < m; j0 += 256) {
+        __syncthreads();
+        tile[threadIdx.x] = (j0 + threadIdx.x < m) ? key[j0 + threadIdx.x] : -INFINITY;
+        __syncthreads();
+        const int lim = (m - j0 < 256) ? (int)(m - j0) : 256;
+        for (int t = 0; t < lim; ++t) {
+            const double kj = tile[t];
+            r += (kj > ki || (kj == ki && j0 + t > i)) ? 1 : 0;
+        }
+    }
+    if (i < m && r < count) out[biased ? r : count - 1 - r] = i;
+}
+}  // namespace
+
+int launch_pool_select(const double* mean, int64_t m, int ny, const double* var, int64_t count, int biased, uint64_t seed,
+                       double* key_ws, int64_t* indices, hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_keys, dim3(1), dim3(1024), 0, s, mean, m, ny, var, biased, seed, key_ws);
+    hipLaunchKernelGGL(k_pool_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, key_ws, m, count, biased, indices);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace nngp

@@ -255,6 +255,22 @@ class GPModel:
         return mean if out is None else (mean, out)
 
 
+    def select_pool(self, x_pool, count: int, biased: bool = False, seed: int = 10):
+        """Pool scoring of the active-learning loop ON THE DEVICE (reference: active/ActiveLearner.py:43-55): predict mean and
+        variance of the pool queries, score = std / max(mean), and return `count` indices -- the largest scores in ascending
+        order (``np.argsort(score)[-count:]``), or, ``biased``, a score-proportional draw without replacement (Gumbel top-k on
+        the counter-based generator of synth.py, seed 10 like the reference's PRNGKey(10)).  Only the indices leave the GPU."""
+        import torch
+        mean, var = self.predict(x_pool, cov="diag", as_numpy=False)
+        m = int(mean.shape[0])
+        count = min(int(count), m)
+        idx = torch.empty((count,), dtype=torch.int64, device=self.device)
+        if count > 0:
+            self._check(self.lib.nngp_pool_select(_lib.ptr(mean), m, self.ny, _lib.ptr(var), count, int(bool(biased)), int(seed),
+                                                  _lib.ptr(idx), _lib.stream_ptr()))
+        return idx.cpu().numpy()
+
+
 def _wrap_device(address: int, count: int, device, typestr: str):
     """Zero-copy torch view of library-owned HBM (typestr '<f8' or '<f4')."""
     import torch

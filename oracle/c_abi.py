@@ -134,3 +134,13 @@ def kernel_build(x1, x2, get, w_std, b_std, rows=None, dtype=np.float64):
     _check(lib().nngp_kernel_build(_p(x1), n1, _p(x2c), n2, d, ctypes.byref(arch), 1 if dtype == np.float64 else 0,
                                    args[0], args[1], n2, r0, r1, None))
     return out
+
+
+def pool_select(mean, var, count, biased=False, seed=10):
+    """nngp_pool_select of the host build: indices of the pool queries the active-learning loop moves to the training set."""
+    mean = _c(np.asarray(mean).reshape(len(var), -1))
+    var = _c(var)
+    idx = np.empty((int(count),), dtype=np.int64)
+    _check(lib().nngp_pool_select(_p(mean), mean.shape[0], mean.shape[1], _p(var), int(count), int(bool(biased)), int(seed),
+                                  idx.ctypes.data_as(ctypes.c_void_p), None))
+    return idx

@@ -350,6 +350,40 @@ int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clampe
 int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n, int64_t k, float alpha, float beta, int32_t lower_only, void* stream) { (void)c; (void)ldc; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)lower_only; (void)stream; NOT_HERE("nngp_gemm_nt_f32"); }
 int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n, int64_t k, float alpha, float beta, float scale, int32_t lower_only, void* stream) { (void)c; (void)ldc; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)scale; (void)lower_only; (void)stream; NOT_HERE("nngp_gemm_nt_h3"); }
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda, const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, void* stream) { (void)c; (void)ldc; (void)cin; (void)ldcin; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)stream; NOT_HERE("nngp_gemm_nt_f64"); }
+/* pool scoring: the same keys (counter-based generator) and the same order as the device kernels */
+static uint64_t splitmix64_host(uint64_t seed, uint64_t idx) {
+    uint64_t z = (idx + 1ULL) * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased, uint64_t seed,
+                     int64_t* indices, void* stream) {
+    (void)stream;
+    if (mean == NULL || var == NULL || indices == NULL || m <= 0 || ny < 1 || count < 0 || count > m) return fail(-2, "pool_select: bad arguments");
+    double* key = (double*)malloc(sizeof(double) * (size_t)m);
+    if (key == NULL) return fail(-2, "pool_select: out of memory");
+    double mx = -INFINITY;
+    for (int64_t i = 0; i < m; ++i) mx = fmax(mx, mean[i * ny]);
+    for (int64_t i = 0; i < m; ++i) {
+        const double sc = sqrt(fmax(var[i], 0.0)) / mx;
+        double k = sc;
+        if (biased) {
+            double u = (double)(splitmix64_host(seed, (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
+            if (u < 1.1102230246251565e-16) u = 1.1102230246251565e-16;
+            k = (sc > 0.0) ? log(sc) - log(-log(u)) : -INFINITY;
+        }
+        key[i] = (k == k) ? k : -INFINITY;
+    }
+    for (int64_t i = 0; i < m; ++i) {
+        int64_t r = 0;
+        for (int64_t j = 0; j < m; ++j) r += (key[j] > key[i] || (key[j] == key[i] && j > i)) ? 1 : 0;
+        if (r < count) indices[biased ? r : count - 1 - r] = i;
+    }
+    free(key);
+    return 0;
+}
+
 int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream) { (void)a; (void)lda; (void)n; (void)x; (void)y; (void)diag_add; (void)stream; NOT_HERE("nngp_symv_f64"); }
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n, void* stream) { (void)b; (void)ldb; (void)m; (void)l; (void)ldl; (void)dinv; (void)n; (void)stream; NOT_HERE("nngp_trsm_rlt_f32"); }
 int nngp_comm_unique_id(void* id128) { (void)id128; NOT_HERE("nngp_comm_unique_id"); }

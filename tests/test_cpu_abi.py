@@ -97,3 +97,26 @@ def test_host_build_carries_the_line_encoder(golden_dir):
         return
     assert lib.nngp_encoder_dim(h) > 0
     assert lib.nngp_encoder_destroy(h) == 0
+
+
+def test_pool_select_host_build_against_numpy():
+    """nngp_pool_select (active/ActiveLearner.py:43-55): score = std / max(mean); the top `count` scores in ascending order are
+    np.argsort(score)[-count:], and the score-proportional draw without replacement is a Gumbel top-k on the counter-based
+    generator of synth.py -- re-stated here in NumPy."""
+    rng = np.random.default_rng(5)
+    m, count = 700, 150
+    mean = rng.uniform(0.5, 19.0, size=(m, 1))
+    var = rng.uniform(0.0, 2.0, size=m) ** 2
+    var[::97] = 0.0
+    score = np.sqrt(var) / mean.max(0)
+    got = c_abi.pool_select(mean, var, count)
+    np.testing.assert_array_equal(got, np.argsort(score, kind="stable")[-count:])
+    u = np.maximum(synth.uniform01(10, np.arange(m, dtype=np.uint64)), 2.0 ** -53)
+    with np.errstate(divide="ignore"):
+        key = np.where(score > 0, np.log(score) - np.log(-np.log(u)), -np.inf)
+    want = np.argsort(-key, kind="stable")[:count]
+    np.testing.assert_array_equal(c_abi.pool_select(mean, var, count, biased=True, seed=10), want)
+    # the draw follows the scores: the selected half carries more score mass than the rest
+    sel = c_abi.pool_select(mean, var, m // 2, biased=True, seed=3)
+    assert len(set(sel.tolist())) == m // 2 and score[sel].mean() > 1.2 * np.delete(score, sel).mean()
+    assert c_abi.lib().nngp_pool_select(None, 5, 1, None, 2, 0, 0, None, None) != 0

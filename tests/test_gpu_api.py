@@ -13,6 +13,7 @@ import nngp_src_amd as nt
 from nngp_src_amd import encoder as enc, stax, synth, train as train_cli
 from nngp_src_amd.estimator import Estimator
 from nngp_src_amd.model import GPModel
+from nngp_src_amd import _lib as _lib_mod
 
 import gpu_util as G
 
@@ -184,6 +185,11 @@ def test_append_rows_matches_full_refit(n0, b, ncap):
         _, v_inc2 = inc.set_refine(2).predict(xt, cov="diag")
         inc.set_refine(1)
         assert np.allclose(v_inc2, v_ref, rtol=1e-5, atol=1e-9 * np.abs(v_ref).max())
+        # ... and DIRECTLY against the float64 oracle fitted on the concatenated set (not only HIP against HIP)
+        m_or, c_or = o.Posterior(x[:cur], y[:cur], o.make_arch(1), diag_reg=1e-3).predict(xt, "nngp", True)
+        assert G.mean_gate(m_inc, m_or)[0] < 1e-6
+        np.testing.assert_allclose(v_inc, np.diag(c_or), rtol=3e-4, atol=1e-9 * np.abs(c_or).max())
+        np.testing.assert_allclose(v_inc2, np.diag(c_or), rtol=1e-4, atol=1e-9 * np.abs(c_or).max())
         # the train-train kernel in HBM is the full symmetric matrix of the concatenated set
         k_inc, ld = inc.kernel_buffer()
         k_ref, ld_ref = ref.kernel_buffer()
@@ -432,3 +438,30 @@ def test_fit_and_predict_are_bitwise_reproducible(get, n, d):
         model.close()
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_pool_select_on_the_device_matches_the_host_build(golden_dir):
+    """the pool scoring of the active-learning loop runs on the GPU (nngp_pool_select) -- only the selected
+    indices travel.  Against the host build of the same entry point on the oracle's posterior (top-k: identical up to ties at
+    the boundary; score-proportional draw: the same counter-based keys, so the same draw wherever the scores agree)."""
+    from oracle import c_abi
+    g = np.load(os.path.join(golden_dir, "forest_n1000_m200.npz"))
+    X, Y = g["X_train"], g["Y_train"]
+    Xtr, Ytr, Xpool = X[:300], Y[:300], X[300:1000]
+    model = GPModel(300, X.shape[1], [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(Xtr, Ytr)
+    m_ref, c_ref = o.Posterior(Xtr, Ytr, o.make_arch(1), diag_reg=1e-3).predict(Xpool, "nngp", True)
+    v_ref = np.diag(c_ref)
+    for biased in (False, True):
+        got = model.select_pool(Xpool, 150, biased=biased, seed=10)
+        want = c_abi.pool_select(m_ref, v_ref, 150, biased=biased, seed=10)
+        assert got.shape == (150,) and len(set(got.tolist())) == 150
+        assert len(set(got.tolist()) ^ set(want.tolist())) <= 2, (biased, len(set(got.tolist()) ^ set(want.tolist())))
+    # the device kernels on the oracle's own numbers: exactly the host build's indices, in order
+    lib = _lib_mod.load()
+    md, vd = _lib_mod.to_device_f64(np.ascontiguousarray(m_ref), G.dev()), _lib_mod.to_device_f64(np.ascontiguousarray(v_ref), G.dev())
+    for biased in (0, 1):
+        idx = torch.empty((150,), dtype=torch.int64, device=md.device)
+        _lib_mod.check(lib.nngp_pool_select(_lib_mod.ptr(md), md.shape[0], 1, _lib_mod.ptr(vd), 150, biased, 10, _lib_mod.ptr(idx),
+                                            _lib_mod.stream_ptr()))
+        np.testing.assert_array_equal(idx.cpu().numpy(), c_abi.pool_select(m_ref, v_ref, 150, biased=bool(biased), seed=10))
+    model.close()

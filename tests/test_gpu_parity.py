@@ -590,6 +590,10 @@ def test_ntk_on_the_lookahead_path_and_append():
     m2, v2 = ref.predict(xt, cov="diag")
     assert np.allclose(m1, m2, rtol=1e-8, atol=1e-8 * np.abs(m2).max())
     np.testing.assert_allclose(v1, v2, rtol=1e-5, atol=1e-8 * np.abs(v2).max())
+    # the appended fit directly against the float64 oracle on the concatenated set
+    m_or, c_or = o.Posterior(x, y, a, diag_reg=1e-3).predict(xt, "ntk", True)
+    assert G.mean_gate(m1, m_or)[0] < 1e-6
+    np.testing.assert_allclose(v1, np.diag(c_or), rtol=1e-4, atol=1e-8 * np.abs(c_or).max())
     model.close(); ref.close()
 
 
