@@ -158,7 +158,12 @@ int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
 /* ---- a4: predict_fn(x_test, get, compute_cov) --------------------------------------------------
  * Replaces predict_fn(x_test=..., get=..., compute_cov=True) (train.py:157-158; estimator.py:66-67).
  * x_test: [mt, d] f64, or NULL for x_test=None (predict on the training rows, estimator.py:37-40).
- * mean: [mt, ny] f64.  cov_mode DIAG: var_or_cov is [mt] f64; FULL: [mt, mt] f64; NONE: ignored.   */
+ * mean: [mt, ny] f64.  cov_mode DIAG: var_or_cov is [mt] f64; FULL: [mt, mt] f64; NONE: ignored.
+ * Asynchronous on `stream` with two exceptions, both small read-backs followed by a wait for the call's own covariance work:
+ * an NTK covariance whose alpha solve took fewer than 6 CG iterations reads the sweeps' 16-byte error estimate
+ * (nngp_model_sweep_estimate), and any covariance whose alpha solve took fewer than 3 iterations reads the 4-byte row flag
+ * (see nngp_model_set_refine).  The estimate is calibrated for the default two NTK sweeps; at levels >= 3 it describes the
+ * first two corrections only and errs on the side of continuing by CG.   */
 int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode,
                        double* mean, double* var_or_cov, void* stream);
 

@@ -728,6 +728,31 @@ def test_random_sweep_against_the_float64_oracle(seed):
     assert row["var_max_rel"] < 3e-4, row
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_level2_variances_keep_the_tighter_gates(seed):
+    """The default covariance level went from 2 to 1 in round 2 and the sweep's gates were widened with it (variance 1e-4 ->
+    3e-4, mean 1e-5 -> 3e-5 elementwise).  Level 2 (one float64 correction sweep + the second-order formula) is still a
+    supported setting: the same random cases at set_refine(2) against the float64 oracle at the gates the sweep had before."""
+    c = _sweep_case(seed)
+    if c["get"] != "nngp":
+        pytest.skip("NNGP cases only (the NTK covariance always runs two sweeps)")
+    if c["absolute"]:
+        c["diag_reg"] *= 1e5
+    x, y = synth.synthetic_queries(c["n"], c["d"], seed=seed, join_block=c["join"] and c["d"] >= 8)
+    xt, _ = synth.synthetic_queries(c["m"], c["d"], seed=seed + 100, join_block=c["join"] and c["d"] >= 8)
+    a = o.make_arch(c["n_relu"], c["w"], c["b"])
+    model = GPModel(c["n"], c["d"], a.w_std, a.b_std, get="nngp", diag_reg=c["diag_reg"], diag_reg_absolute_scale=c["absolute"]).fit(x, y)
+    model.set_refine(2)
+    mean, var = model.predict(xt, cov="diag")
+    ref = c_oracle.fit(x, y, a.w_std, a.b_std, diag_reg=c["diag_reg"], absolute=c["absolute"])
+    mean_ref, var_ref = c_oracle.predict_nngp(ref, xt, 1)
+    prior = o.diag_kernel(np.sum(xt * xt, axis=1) / c["d"], a)[0].max()
+    l2, elem = G.mean_gate(mean, mean_ref)
+    vrel = float(np.max(np.abs(var - var_ref.ravel()) / np.maximum(np.abs(var_ref.ravel()), 1e-9 * np.abs(var_ref).max() + 1e-11 * prior)))
+    model.close()
+    assert l2 < 1e-6 and elem < 1e-5 and vrel < 1e-4, (c, l2, elem, vrel)
+
+
 def test_adaptive_covariance_when_the_alpha_solve_says_nothing():
     """The ill-conditioned fit of the sweep (seed 6: d=3, 4-layer, diag_reg=1e-4, cond 2.6e7) with y = 0: the alpha solve
     converges at once, so only the row flag can tell that the fixed sweeps were not enough.  The covariance does not
