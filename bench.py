@@ -335,7 +335,7 @@ def main():
             torch.cuda.synchronize()
             if ktimer["on"]:  # HIP events the library put around every trailing-update launch of this step's factorisation
                 nl, tms, tfl = model.update_timer_read()
-                ktimer["launches"] += nl; ktimer["ms"] += tms; ktimer["flops"] += tfl
+                ktimer["launches"] += nl; ktimer["ms"] += tms; ktimer["flops"] += tfl; ktimer["bytes"] += model.update_timer_bytes()
             for k, (a, b) in {"set_train": (e0, e1), "kernel_build": (e1, e2), "allgather": (e2, e3),
                               "cholesky": (e3, e4), "alpha_solve": (e4, e5), "posterior": (e5, e6)}.items():
                 stages.setdefault(k, []).append(a.elapsed_time(b))
@@ -354,7 +354,7 @@ def main():
         return [float(v) for v in t.tolist()]
 
     # live timing of the dominant kernel (k_gemm_nt_h3, the Cholesky's split-float16 trailing update) for `roofline`
-    ktimer = {"on": False, "launches": 0, "ms": 0.0, "flops": 0.0}
+    ktimer = {"on": False, "launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
     if not (shard and dist_chol):
         try:
             model.update_timer(True)
@@ -413,7 +413,7 @@ def main():
     if os.path.exists(tpath):  # HBM bytes of the Cholesky kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
         _pm = json.load(open(tpath))
         traffic = _pm.get("cholesky_bytes")
-        _k = _pm.get("kernels", {}).get("k_gemm_nt_h3<true>")
+        _k = _pm.get("kernels", {}).get("k_gemm_nt_h3v2<true>") or _pm.get("kernels", {}).get("k_gemm_nt_h3<true>")
         if _k and _k.get("calls"):
             k_traffic = (_k["fetch_bytes"] + _k["write_bytes"]) / _k["calls"]
         traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
@@ -483,14 +483,16 @@ def main():
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(k_tflops, 3), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s",
                 "frac": round(k_tflops / (PEAK_F16_MFMA_TFLOPS / 3), 4),
-                "traffic": k_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_h3<true>, per launch") if k_traffic else None,
-                "kernel": "k_gemm_nt_h3<LOWER=true> (split-float16 trailing update of the blocked Cholesky)",
+                "traffic": k_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_h3v2<true>, per launch") if k_traffic else None,
+                "traffic_over_algorithmic": round(k_traffic / (ktimer["bytes"] / ktimer["launches"]), 3) if k_traffic else None,
+                "kernel": "k_gemm_nt_h3v2<LOWER=true> (split-float16 updates of the grouped look-ahead Cholesky: K = 1024 inside a group "
+                          "of 4 block columns, K = 4096 beyond it)",
                 "launches_per_step": round(per_step, 2), "avg_launch_ms": round(ktimer["ms"] / ktimer["launches"], 4),
                 "ms_per_step_in_kernel": round(ktimer["ms"] / args.steps, 3),
                 "algorithmic_flops_per_launch": round(ktimer["flops"] / ktimer["launches"], 1),
-                "algorithmic_bytes_per_launch": round((8.0 * ktimer["flops"] / ktimer["launches"] / (2.0 * 1024)) , 1),
-                "bytes_note": "C read + written once per launch (8 B per updated float32 entry, entries = flops / (2 x 1024)); the "
-                              "operand panels add 4 B x rows x 1024 once",
+                "algorithmic_bytes_per_launch": round(ktimer["bytes"] / ktimer["launches"], 1),
+                "bytes_note": "C read + written once per launch (8 B per updated float32 entry) + the operands' split rows once (4 B per "
+                              "row and k): nngp_model_update_timer_bytes",
                 "executed_f16_mfma_tflops": round(3 * k_tflops, 1),
                 "peak_note": "dense f16 MFMA peak %.1f TF/s / 3 products per float32-grade term" % PEAK_F16_MFMA_TFLOPS,
                 "timer": "HIP events on the update stream around each launch (library: nngp_model_update_timer), timed steps only",

@@ -152,6 +152,9 @@ int nngp_model_info(nngp_model* m, nngp_fit_info* info /* host */);
  * float16 MFMA products per term).  Any out pointer may be NULL. */
 int nngp_model_update_timer(nngp_model* m, int32_t enable);
 int nngp_model_update_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total);
+/* ... and their algorithmic bytes: C read and written once per launch (8 B per updated float32 entry) plus the operands' split
+ * rows once (4 B per row and k) -- what a launch must move at least, for the roofline's `traffic` comparison. */
+int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total);
 /* alpha = (K + reg I)^-1 Y, [n, ny] f64, copied to a device buffer. */
 int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
 

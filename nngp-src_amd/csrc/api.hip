@@ -948,6 +948,14 @@ int nngp_model_update_timer_read(nngp_model* m, int64_t* launches, double* ms_to
     return 0;
 }
 
+int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total) {
+    NNGP_REQUIRE(m != nullptr && m->la != nullptr && bytes_total != nullptr, "update_timer_bytes: no timer on this model");
+    double b = 0.0;
+    for (int t = 0; t < m->la->tu_count; ++t) b += m->la->tu_bytes[t];
+    *bytes_total = b;
+    return 0;
+}
+
 int nngp_model_info(nngp_model* m, nngp_fit_info* info) {
     NNGP_REQUIRE(m != nullptr && info != nullptr, "model_info: NULL argument");
     NNGP_TRY(run_pending_solve(m, nullptr, false));

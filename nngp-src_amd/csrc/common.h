@@ -174,6 +174,7 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     hipEvent_t tu0[kMaxTimed] = {}, tu1[kMaxTimed] = {};
     int tu_count = 0;              // launches of the last factorisation
     double tu_flops[kMaxTimed] = {};
+    double tu_bytes[kMaxTimed] = {};  // algorithmic bytes: C read + written once (8 B per updated entry) + the split rows of the operands once
 };
 int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);

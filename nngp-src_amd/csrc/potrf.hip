@@ -682,6 +682,7 @@ static int h3_update_timed(LookAhead* la, float* c, int64_t ldc, const char* a, 
         const int t = la->tu_count++;
         NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
         la->tu_flops[t] = 2.0 * entries * ((double)np * (double)k - (double)lead);
+        la->tu_bytes[t] = 8.0 * entries + 4.0 * ((double)m + (double)n) * ((double)np * (double)k - (double)lead);
     }
     return 0;
 }
@@ -761,6 +762,9 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
             const int t = la->tu_count++;
             NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
             la->tu_flops[t] = 2.0 * entries * ((double)far.np * (double)nb - (double)lead);
+            double rows_cols = 0.0;
+            for (int r = 0; r < nreg; ++r) rows_cols += (double)reg[r].m + (double)reg[r].n;
+            la->tu_bytes[t] = 8.0 * entries + 4.0 * rows_cols * ((double)far.np * (double)nb - (double)lead);
         }
         if (lead > 0) {  // columns [0, lead) of block column 0
             for (int r = 0; r < nreg; ++r) {
@@ -1007,6 +1011,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
                     NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
                     // entries on or below the diagonal in rows [nb2, m) of the m x m trailing matrix
                     la->tu_flops[t] = 2.0 * (0.5 * ((double)m * (m + 1) - (double)nb2 * (nb2 + 1))) * (double)(nbk - lead);
+                    la->tu_bytes[t] = 8.0 * (0.5 * ((double)m * (m + 1) - (double)nb2 * (nb2 + 1))) + 4.0 * (2.0 * (double)m - (double)nb2) * (double)(nbk - lead);
                 }
                 if (rc == 0 && lead > 0)
                     rc = launch_gemm_nt_f32(c + nb2 * ld, ld, p + nb2 * ld, ld, p, ld, m - nb2, nb2, lead, -1.0f, 1.0f, false, la->update);

@@ -222,6 +222,12 @@ class GPModel:
         self._check(self.lib.nngp_model_update_timer_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
         return int(n.value), float(ms.value), float(fl.value)
 
+    def update_timer_bytes(self):
+        """Algorithmic bytes of those launches (C read + written once, operand split rows once)."""
+        b = ctypes.c_double(0.0)
+        self._check(self.lib.nngp_model_update_timer_bytes(self.handle, ctypes.byref(b)))
+        return float(b.value)
+
     def alpha(self):
         import torch
         out = torch.empty((self.n, self.ny), dtype=torch.float64, device=self.device)

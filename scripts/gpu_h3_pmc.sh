@@ -13,9 +13,15 @@ import csv, glob, collections, os
 R = os.environ["GRAFT_REPO_ROOT"]
 agg = collections.defaultdict(list)
 for f in glob.glob(R + "/gpurun_out/h3pmc_*/**/*counter_collection*.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "k_gemm_nt_h3" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = [r for r in csv.DictReader(open(f)) if "k_gemm_nt_h3" in r["Kernel_Name"]]
+    by_counter = collections.defaultdict(list)
+    for r in rows:
+        by_counter[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    for c, v in by_counter.items():
+        v.sort()
+        half = len(v) // 2  # scripts/h3_one.py: first the K = 1024 launches, then the K = 4096 ones
+        agg[("K1024", c)] += [x for _, x in v[:half]]
+        agg[("K4096", c)] += [x for _, x in v[half:]]
 for k, v in sorted(agg.items()):
-    print(k, "n=%d" % len(v), "last=%.4g" % v[-1], "mean=%.4g" % (sum(v) / len(v)))
+    print(k[0], k[1], "n=%d" % len(v), "last=%.4g" % v[-1], "mean=%.4g" % (sum(v) / len(v)))
 PY

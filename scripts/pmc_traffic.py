@@ -28,10 +28,10 @@ def short(name):
         return "k_build_mfma"
     for key in ("k_gemm_nt_f32<2, 2, false>", "k_gemm_nt_f32<2, 2, true>", "k_gemm_nt_f32<1, 2, false>", "k_gemm_nt_f32<1, 1, false>",
                 "k_gemm_nt_f32<1, 1, true>", "k_gemm_nt_f64", "k_potrf_leaf", "k_build", "k_gemv_f64", "k_gemv_n_f32",
-                "k_gemv_t_partial_f32", "k_factor_input", "k_transpose_f32", "k_gemm_nt_h3<true>", "k_gemm_nt_h3<false>", "k_split_rows",
+                "k_gemv_t_partial_f32", "k_factor_input", "k_transpose_f32", "k_gemm_nt_h3v2<true", "k_gemm_nt_h3v2<false", "k_gemm_nt_h3<true>", "k_gemm_nt_h3<false>", "k_split_rows",
                 "k_trsm_panel_f32", "k_trsm_panel_h3", "k_split_diag_frag", "k_symv_tiles_f64", "k_symv_reduce_f64", "k_split_lower_t"):
         if key in name:
-            return key
+            return {"k_gemm_nt_h3v2<true": "k_gemm_nt_h3v2<true>", "k_gemm_nt_h3v2<false": "k_gemm_nt_h3v2<false>"}.get(key, key)
     return None
 
 
@@ -51,7 +51,7 @@ def main():
             continue
         e = out["kernels"].setdefault(k, {"calls": calls, "fetch_bytes": 0.0, "write_bytes": 0.0})
         e["write_bytes"] += kib * 1024
-    chol = [k for k in out["kernels"] if k.startswith("k_gemm_nt_f32") or k in ("k_potrf_leaf", "k_gemm_nt_h3<true>", "k_split_rows", "k_trsm_panel_f32", "k_trsm_panel_h3", "k_split_diag_frag")]
+    chol = [k for k in out["kernels"] if k.startswith("k_gemm_nt_f32") or k in ("k_potrf_leaf", "k_gemm_nt_h3<true>", "k_gemm_nt_h3v2<true>", "k_split_rows", "k_trsm_panel_f32", "k_trsm_panel_h3", "k_split_diag_frag")]
     out["cholesky_bytes_note"] = ("trailing updates (k_gemm_nt_h3<true>) + fused panel solves + float32 GEMMs + leaf + split kernels of the step "
                                   "(the posterior's few float32 GEMMs included; its split-float16 solves, k_gemm_nt_h3<false>, are not). "
                                   "FETCH_SIZE counts what leaves L2 toward the fabric, Infinity-Cache hits included (MI355X_MICROARCH.md), so this is "
