@@ -117,7 +117,7 @@ def cpu_baseline(n_bench, d, m, n_relu, gpu_ms):
 def bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, m, desc):
     """Opt-in comparison layout: the 2-D block-cyclic fit of nngp-src_amd/dist2d.py.  A step = build of the
     rank's own tiles + distributed Cholesky + distributed CG for alpha + mean and level-1 variance of the test queries (replicated
-    right-hand-side blocks of 128).  Correctness-first code: one float32 GEMM per trailing update, torch glue between kernels."""
+    right-hand-side blocks of 128).  Correctness-first code: one trailing update per block column (split-float16 from the second column on), torch glue between kernels."""
     import torch
     import torch.distributed as dist
     from nngp_src_amd import dist2d
@@ -148,7 +148,7 @@ def bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, 
             "metric": "NNGP kernel-build + GP-solve wall-clock (ms) and GFLOP/s at N train queries",
             "value": round(fl["total"] / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (tile Cholesky and updates on the float32 MFMA; f64 build/CG/means)", "data": "synthetic",
+            "dtype": "f32 (tile Cholesky; trailing updates as split f16 x3 from the second block column on; f64 build/CG/means)", "data": "synthetic",
             "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": mt,
                        "parallelism": "2-D block-cyclic %d x %d (tiles of 1024): no rank holds the whole kernel or factor; panel broadcasts "
                                       "along process rows, exchanges inside process columns, fan-in triangular solves" % (pr, pc)},

@@ -195,6 +195,19 @@ class HipOps:
                                           float(beta), 0, L.stream_ptr()), self.lib)
         return c
 
+    def gemm_nt_h3(self, c, a, b, alpha, beta, scale):
+        """The same product on the float16 matrix pipe with float32-grade operands (nngp_gemm_nt_h3: hi + lo float16 planes,
+        three products per term; `scale` a power of two with max |a|, |b| * scale < 2^15): the trailing updates of the
+        distributed factorisation, 3/16 of the float32-MFMA time per term."""
+        L = self._lib
+        m, k = a.shape
+        n = b.shape[0]
+        if m == 0 or n == 0 or k == 0:
+            return c
+        L.check(self.lib.nngp_gemm_nt_h3(L.ptr(c), c.stride(0), L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), m, n, k, float(alpha),
+                                         float(beta), float(scale), 0, L.stream_ptr()), self.lib)
+        return c
+
     def gemm_nt64(self, c, a, b, alpha, beta):
         """The same in float64 (float64 MFMA)."""
         L = self._lib
@@ -231,6 +244,10 @@ class Dist2DGP:
         dn, dg = ops.kernel_diag(self.x)
         self.trace_mean = float(dg.mean().item())
         self.reg = float(diag_reg) if diag_reg_absolute_scale else float(diag_reg) * self.trace_mean
+        # float16-pipe trailing updates: |L_ij| <= sqrt(max_i A_ii), scaled below 2^15 by a power of two (as SplitWork::scale)
+        dmax = float(dg.max().item()) + self.reg + self.trace_mean
+        self.h3_scale = 2.0 ** (14 - int(np.ceil(np.log2(max(np.sqrt(dmax), 1e-30)))))
+        self.h3_min_tiles = 96
         self.minv, self.tinv = {}, {}  # L_JJ^-1 and L_JJ^-T of the diagonal tiles this rank owns
         self.clamped = 0
         self.alpha = None
@@ -304,7 +321,14 @@ class Dist2DGP:
             # transposed operand: tiles L_Jk with J = pc (mod Pc), J > k, collected inside this process column
             pcol = self._column_panel(k, prow, i0, j0, mc)
             if mr > 0 and mc > 0:  # ONE update of the local trailing tiles (upper ones included: never read)
-                ops.gemm_nt(self.a32[i0 * nb:, j0 * nb:], prow, pcol, -1.0, 1.0)
+                # on the float16 pipe from the second block column on, when the local tiles fill the GPU (>= 96 tiles of 256 x 256,
+                # as in the single-GPU solves); block column 0 -- the kernel's dominant, one-signed columns -- stays float32
+                # (accumulator truncation of the float16 pipe on same-sign sums: potrf.hip)
+                h3 = getattr(ops, "gemm_nt_h3", None)
+                if h3 is not None and k > 0 and nb % 32 == 0 and ((mr + 255) // 256) * ((mc + 255) // 256) >= self.h3_min_tiles:
+                    h3(self.a32[i0 * nb:, j0 * nb:], prow, pcol, -1.0, 1.0, self.h3_scale)
+                else:
+                    ops.gemm_nt(self.a32[i0 * nb:, j0 * nb:], prow, pcol, -1.0, 1.0)
         self.clamped = int(comm.allreduce_sum(t.tensor([self.clamped], dtype=t.int64, device=self.a32.device)).item()) if comm.on else self.clamped
         return self
 
