@@ -124,7 +124,7 @@ struct H3RegionSpec {
 };
 int launch_gemm_nt_h3r(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
                        const H3RegionSpec* spec, int nreg, int64_t k, float alpha, float beta, bool lower_only, int* counters,
-                       int reserve_cus, hipStream_t s, const float* row_alpha = nullptr);
+                       int reserve_cus, hipStream_t s, const float* row_alpha = nullptr, int helper = 0);
 int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
                        int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int64_t diag_shift, int* counters,
                        int reserve_cus, hipStream_t s, const float* row_alpha = nullptr);  // sum over npanels panels, one pass over C
@@ -168,6 +168,7 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     bool masked = false;  // streams own disjoint CU sets (hipExtStreamCreateWithCUMask)
     hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
     hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};
+    hipEvent_t ev_chunk[kMaxSteps] = {}, ev_helper[kMaxSteps] = {};  // grouped form: a far chunk may start / its helper grid has finished
     // live timing of the split-float16 trailing updates (nngp_model_update_timer): event pairs around each launch
     static constexpr int kMaxTimed = 320;  // split-float16 update launches of one factorisation (grouped form: ~3 per block column)
     bool time_updates = false;

@@ -419,7 +419,7 @@ template <bool LOWER, int ABL>
 __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, const char* A, const char* B, int64_t ldp,
                                                       int64_t pstride, int npanels, int nk_first, int first_off, H3Regions regs, int nk,
                                                       float alpha, float beta, int order_br, int order_bc,
-                                                      int* counters, int slots_per_xcd, const float* row_alpha) {
+                                                      int* counters, int slots_per_xcd, const float* row_alpha, int total_wgs) {
     constexpr int ablate = ABL;
     // ONE object (see k_gemm_nt_h3), all 160 KB: two operand stages of 64 KB; in the epilogue 20 KB of C staging per wave.  The
     // work-slot word is only touched between a tile's last fragment read and its epilogue, when nothing else lives in LDS.
@@ -810,7 +810,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_h3v2(float* C, int64_t ldc, con
 #endif
 #undef H3_STAMP
     // The work counters reset themselves: the last workgroup to run out of work zeroes them for the next launch (see k_gemm_nt_h3)
-    if (tid == 0 && atomicAdd(&counters[8], 1) == (int)gridDim.x - 1)
+    // (total_wgs: the workgroups of ALL launches that share this pass -- the update-stream grid and, in the Cholesky, a helper grid
+    // that joins it on the panel stream once the diagonal-block chain has released the reserved compute units)
+    if (tid == 0 && atomicAdd(&counters[8], 1) == total_wgs - 1)
         for (int i = 0; i < 9; ++i) __hip_atomic_store(&counters[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -861,9 +863,12 @@ int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, floa
 // columns of SplitWork::planes); the earliest panel contributes its columns [lead, k) only.  One pass over C for the whole sum.
 constexpr int kH3DefaultForm = 2;  // 1: k_gemm_nt_h3 (32x32x16), 2: k_gemm_nt_h3v2 (16x16x32, balanced loads); debug key 5 = 40 + form
 
+// helper: 0 = one launch; 1 = this launch will be joined by a helper grid of `reserve_cus` workgroups (launched with helper = 2 and
+// the SAME other arguments on another stream, ordered after everything this pass depends on): both pull tiles from the same
+// counters, and the counters reset when the workgroups of both have finished.
 int launch_gemm_nt_h3r(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t pstride, int npanels, int64_t lead,
                        const H3RegionSpec* spec, int nreg, int64_t k, float alpha, float beta, bool lower_only, int* counters,
-                       int reserve_cus, hipStream_t s, const float* row_alpha) {
+                       int reserve_cus, hipStream_t s, const float* row_alpha, int helper) {
     NNGP_REQUIRE(nreg >= 1 && nreg <= 4 && spec != nullptr, "gemm_nt_h3: 1 to 4 regions per launch");
     NNGP_REQUIRE(k > 0 && k % 32 == 0, "gemm_nt_h3: k must be a multiple of 32 (k=%lld)", (long long)k);
     NNGP_REQUIRE(ldp >= 4 * k && ldp % 16 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && counters != nullptr,
@@ -919,12 +924,18 @@ int launch_gemm_nt_h3r(float* c, int64_t ldc, const char* a, const char* b, int6
     if (grid > slots_per_xcd * 8) grid = slots_per_xcd * 8;
     grid = (grid / 8) * 8;  // the same number of workgroups on every XCD
     if (grid < 8) grid = 8;
+    int total_wgs = (int)grid;
+    if (helper != 0) {
+        NNGP_REQUIRE(form == 2 && reserve_cus >= 8 && reserve_cus % 8 == 0, "gemm_nt_h3: a helper grid needs form 2 and reserved compute units");
+        total_wgs = (int)grid + reserve_cus;
+        if (helper == 2) grid = reserve_cus;
+    }
     const int ablate = NNGP_KNOB(0) & 507;  // 1 no loads, 2 no MFMA, 8 no C traffic; form 2 also: 16 no C loads, 32 no C stores
     if (form == 2) {
 #define NNGP_H3V2_LAUNCH(LOW, ABL)                                                                                                  \
     hipLaunchKernelGGL((k_gemm_nt_h3v2<LOW, ABL>), dim3((unsigned)grid), dim3(512), 0, s, c, ldc, a, b, ldp, pstride, npanels,          \
                        (int)((k - lead) / 32), (int)(lead * 4), regs, (int)(k / 32), alpha, beta, br, bc, counters,                  \
-                       (int)slots_per_xcd, row_alpha)
+                       (int)slots_per_xcd, row_alpha, total_wgs)
 #ifdef NNGP_TIMING_KNOBS
         if (lower_only) {
             switch (ablate) {
@@ -981,7 +992,7 @@ int launch_gemm_nt_h3x(float* c, int64_t ldc, const char* a, const char* b, int6
     NNGP_REQUIRE(ldc >= n && diag_shift % 128 == 0 && diag_shift >= 0, "gemm_nt_h3: bad ldc / diag_shift");
     const H3RegionSpec one = {0, 0, m, n, diag_shift};
     return launch_gemm_nt_h3r(c, ldc, a, b, ldp, pstride, npanels, lead, &one, 1, k, alpha, beta, lower_only, counters, reserve_cus, s,
-                              row_alpha);
+                              row_alpha, 0);
 }
 
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,

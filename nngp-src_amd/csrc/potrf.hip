@@ -620,7 +620,9 @@ int lookahead_create(LookAhead** out) {
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
     for (int i = 0; i < LookAhead::kMaxSteps; ++i)
         if (hipEventCreateWithFlags(&la->ev_panel[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&la->ev_col[i], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&la->ev_col[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&la->ev_chunk[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&la->ev_helper[i], hipEventDisableTiming) != hipSuccess) {
             set_error("hipEventCreate failed");
             return -1;
         }
@@ -635,7 +637,10 @@ void lookahead_destroy(LookAhead* la) {
     (void)hipStreamDestroy(la->panel);
     (void)hipStreamDestroy(la->update);
     (void)hipEventDestroy(la->ev_in); (void)hipEventDestroy(la->ev_panel_done); (void)hipEventDestroy(la->ev_update_done);
-    for (int i = 0; i < LookAhead::kMaxSteps; ++i) { (void)hipEventDestroy(la->ev_panel[i]); (void)hipEventDestroy(la->ev_col[i]); }
+    for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
+        (void)hipEventDestroy(la->ev_panel[i]); (void)hipEventDestroy(la->ev_col[i]);
+        (void)hipEventDestroy(la->ev_chunk[i]); (void)hipEventDestroy(la->ev_helper[i]);
+    }
     for (int i = 0; i < LookAhead::kMaxTimed; ++i) {
         if (la->tu0[i]) (void)hipEventDestroy(la->tu0[i]);
         if (la->tu1[i]) (void)hipEventDestroy(la->tu1[i]);
@@ -718,6 +723,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
     const float ascale = -1.0f / (sw->scale * sw->scale);
     const int reserve = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
     const int64_t lead0 = 64;  // columns of block column 0 that stay on the float32 MFMA (see potrf_lookahead_f32)
+    const bool use_helper = !(NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) && reserve >= 8 && reserve % 8 == 0;  // debug key 2 = 30 + D: no helper grids
     auto plane_rows = [&](int col, int64_t row) { return sw->planes + (int64_t)col * sw->col_stride + row * ldp; };
     auto width = [&](int64_t col0) { return (n - col0 < nb) ? n - col0 : nb; };
     FarWork far;
@@ -725,7 +731,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
     // One launch per chunk: up to three regions of the pending group's far update -- rows [row0, n) x cols [col0, col0 + w), lower
     // trapezoid (col <= row + shift relative to the region's origin) -- with all panels of the group in one pass over C; the
     // group's lead columns go through the float32 GEMM region by region.
-    auto far_chunk = [&]() -> int {
+    auto far_chunk = [&](int step) -> int {
         if (!far.active || far.next >= far.nchunks) return 0;
         const int i = far.next++;
         const int64_t r0 = far.r0;
@@ -756,8 +762,23 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
             if (la->tu1[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu1[t]));
             NNGP_HIP_CHECK(hipEventRecord(la->tu0[t], la->update));
         }
+        // The `reserve` compute units this launch leaves to the panel stream idle once the diagonal-block chain (0.5 ms) is done:
+        // a helper grid of that many workgroups, enqueued on the PANEL stream behind the chain, then joins the pass through the
+        // shared work counters.  It may not start before everything the pass depends on (the update stream up to here), and the
+        // update stream may not go on before it has finished.  Only for passes long enough to outlive the chain.
+        double tiles = 0.0;
+        for (int r = 0; r < nreg; ++r) tiles += trap_entries(reg[r].m, reg[r].n, reg[r].shift) / 65536.0;
+        const bool helper = use_helper && step >= 0 && tiles * (double)far.np >= 4.0 * 3.0 * 224.0;  // >= ~3 rounds of K = 4096 tiles
+        if (helper) NNGP_HIP_CHECK(hipEventRecord(la->ev_chunk[step], la->update));
         NNGP_TRY(launch_gemm_nt_h3r(a, ld, plane_rows(kl, 0), plane_rows(kl, 0), ldp, sw->col_stride, far.np, lead, reg, nreg, nb, ascale, 1.0f,
-                                    true, sw->counters, reserve, la->update));
+                                    true, sw->counters, reserve, la->update, nullptr, helper ? 1 : 0));
+        if (helper) {
+            NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_chunk[step], 0));
+            NNGP_TRY(launch_gemm_nt_h3r(a, ld, plane_rows(kl, 0), plane_rows(kl, 0), ldp, sw->col_stride, far.np, lead, reg, nreg, nb, ascale,
+                                        1.0f, true, sw->counters, reserve, la->panel, nullptr, 2));
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_helper[step], la->panel));
+            NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_helper[step], 0));
+        }
         if (timed) {
             const int t = la->tu_count++;
             NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], la->update));
@@ -796,7 +817,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
         NNGP_HIP_CHECK(hipEventRecord(la->ev_panel[k], la->panel));
         if (rc != 0) break;
         // update stream, while that factorisation runs: the next piece of the previous group's far update
-        rc = far_chunk();
+        rc = far_chunk(k);
         if (rc != 0 || m == 0) break;
         NNGP_HIP_CHECK(hipStreamWaitEvent(la->update, la->ev_panel[k], 0));
         // solve all rows below in one fused launch; it leaves their float16 split copy in this block column's planes
@@ -860,7 +881,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
             }
         }
     }
-    while (rc == 0 && far.active) rc = far_chunk();  // (nothing is left when the loop ran to the last block column)
+    while (rc == 0 && far.active) rc = far_chunk(-1);  // (nothing is left when the loop ran to the last block column)
     if (rc == 0) sw->l_ready = true;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, la->panel));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, la->update));
@@ -888,7 +909,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     if (la == nullptr || NNGP_KNOB(2) == 1 || n < 4 * nb || (n + nb - 1) / nb > LookAhead::kMaxSteps)
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
     // grouped form: deep-K far updates (debug key 2 = 10 + D overrides the group size; D = 1: the round-2 form below)
-    const int group = (NNGP_KNOB(2) >= 11 && NNGP_KNOB(2) <= 26) ? NNGP_KNOB(2) - 10 : kLookAheadGroup;
+    const int group = (NNGP_KNOB(2) >= 11 && NNGP_KNOB(2) <= 26) ? NNGP_KNOB(2) - 10 : (NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) ? NNGP_KNOB(2) - 30 : kLookAheadGroup;
     if (h3 && group > 1 && nb == 1024 && (NNGP_KNOB(2) == 0 || NNGP_KNOB(2) >= 11) && NNGP_KNOB(3) == 0 && ld % 4 == 0)
         return potrf_lookahead_grouped(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
     la->tu_count = 0;
