@@ -136,6 +136,10 @@ int nngp_model_factor_begin(nngp_model* m, void* stream);
 int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* stream);
 int nngp_model_factor_update(nngp_model* m, int64_t panel_col0, int64_t panel_width, int64_t col0, int64_t width,
                              void* stream);
+/* ... the same update for several target block columns at once (HOST array of their first rows / columns, ascending; all of
+ * `width` except possibly the last): the block columns one rank owns go out four to a split-float16 launch. */
+int nngp_model_factor_update_cols(nngp_model* m, int64_t panel_col0, int64_t panel_width, const int64_t* cols, int32_t ncols,
+                                  int64_t width, void* stream);
 int nngp_model_factor_end(nngp_model* m, void* stream);
 /* float32 factor buffer [n_padded, ld] (lower triangle) and the inverted 128-blocks [n_padded/128][128*128]. */
 int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv);

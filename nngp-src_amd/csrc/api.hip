@@ -656,13 +656,20 @@ int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* st
     NNGP_REQUIRE(m != nullptr && m->built, "factor_panel: build the kernel rows first");
     // Exact-arithmetic pivots of K + reg I are >= reg; anything far below is float32 rounding noise.
     return potrf_panel_f32(m->a32, m->np, m->ld, m->dinv, m->clamped, (float)(0.25 * m->reg_fac), col0, width,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, &m->split);
 }
 
 int nngp_model_factor_update(nngp_model* m, int64_t panel_col0, int64_t panel_width, int64_t col0, int64_t width,
                              void* stream) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor_update: build the kernel rows first");
     return potrf_update_f32(m->a32, m->np, m->ld, panel_col0, panel_width, col0, width, (hipStream_t)stream, &m->split);
+}
+
+int nngp_model_factor_update_cols(nngp_model* m, int64_t panel_col0, int64_t panel_width, const int64_t* cols, int32_t ncols,
+                                  int64_t width, void* stream) {
+    NNGP_REQUIRE(m != nullptr && m->built, "factor_update_cols: build the kernel rows first");
+    NNGP_REQUIRE(ncols >= 0 && (ncols == 0 || cols != nullptr), "factor_update_cols: bad column list");
+    return potrf_update_cols_f32(m->a32, m->np, m->ld, panel_col0, panel_width, cols, ncols, width, (hipStream_t)stream, &m->split);
 }
 
 int nngp_model_factor_end(nngp_model* m, void* stream) {

@@ -184,9 +184,11 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
 constexpr int64_t kLookAheadNb = 1024;  // block-column width of the look-ahead Cholesky
 constexpr int kLookAheadGroup = 4;      // block columns per deep-K far update (potrf.hip, grouped form)
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
-                    int64_t w, hipStream_t s);
+                    int64_t w, hipStream_t s, SplitWork* sw = nullptr);
 int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, int64_t o, int64_t w, hipStream_t s,
                      SplitWork* sw = nullptr);  // sw: run the update on the float16 pipe (split copy of the panel kept in sw)
+int potrf_update_cols_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, const int64_t* cols, int ncols, int64_t w,
+                          hipStream_t s, SplitWork* sw = nullptr);  // several target block columns, four to a split-float16 launch
 int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
                  hipStream_t s);
 

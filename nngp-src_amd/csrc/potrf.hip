@@ -1063,14 +1063,31 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
 // ---- block-column pieces of the right-looking factorisation (multi-GPU: block columns are dealt cyclically) ----
 // Factor block column [o, o+w): Cholesky of the diagonal block, then the rows below times its inverse transpose.
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
-                    int64_t w, hipStream_t s) {
+                    int64_t w, hipStream_t s, SplitWork* sw) {
     NNGP_REQUIRE(o >= 0 && w > 0 && o + w <= n && o % TB == 0 && w % TB == 0, "potrf_panel: bad block column");
     float* akk = a + o * ld + o;
     float* dk = dinv + (o / TB) * TB * TB;
     NNGP_TRY(potrf_rec(akk, w, ld, dk, clamped, pivot_floor, s));
     const int64_t m = n - o - w;
-    if (m > 0) NNGP_TRY(trsm_rlt_f32(akk + w * ld, ld, m, akk, ld, dk, w, s));
-    return 0;
+    if (m <= 0) return 0;
+    // rows below: ONE fused launch (trsm_panel.hip) as in the single-GPU look-ahead, on the float16 pipe from the second block
+    // column on; with the model's split workspace it also leaves the rows' split copy in place (the owner's own updates of this
+    // block column then need no separate split pass).  Round 2 ran the 128-wide GEMM recursion here (15 dependent launches).
+    const bool planes_ok = sw != nullptr && sw->planes != nullptr && w == sw->k_cap && o % w == 0 && sw->rows_cap >= n + 256 &&
+                           sw->col_stride >= sw->rows_cap * 4 * sw->k_cap && NNGP_KNOB(2) != 2;
+    if (w <= 1024 && NNGP_KNOB(2) != 4) {
+        const int64_t ldp = planes_ok ? 4 * sw->k_cap : 0;
+        char* rows = planes_ok ? sw->planes + (o / w) * sw->col_stride + (o + w) * ldp : nullptr;
+        if (planes_ok && o > 0 && w == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr && NNGP_KNOB(2) != 5) {
+            NNGP_TRY(launch_split_diag_frag(akk, ld, w, sw->scale, sw->ldiag, dk, sw->dfrag, s));
+            NNGP_TRY(launch_trsm_panel_h3(akk + w * ld, ld, m, sw->ldiag, sw->dfrag, w, rows, ldp, sw->scale, s));
+        } else {
+            NNGP_TRY(launch_trsm_panel_f32(akk + w * ld, ld, m, akk, ld, dk, w, rows, ldp, planes_ok ? sw->scale : 1.0f, s));
+        }
+        if (planes_ok) sw->split_panel = o;
+        return 0;
+    }
+    return trsm_rlt_f32(akk + w * ld, ld, m, akk, ld, dk, w, s);
 }
 
 // Apply the finished block column [po, po+pw) to block column [o, o+w), o >= po + pw:
@@ -1107,6 +1124,53 @@ int potrf_update_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, in
     if (below > 0)
         NNGP_TRY(launch_gemm_nt_f32(c + w * ld, ld, p + w * ld, ld, p, ld, below, w, pw, -1.0f, 1.0f, false, s));
     return 0;
+}
+
+// The same for SEVERAL target block columns of one rank (multi-GPU: the block columns a rank owns, dealt cyclically): the columns
+// that qualify for the float16 pipe go out four to a launch (regions of one split-float16 pass: fewer launches, fewer tails), the
+// others one by one as above.  cols: first rows / columns of the targets, ascending, all of width w except possibly the last.
+int potrf_update_cols_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t pw, const int64_t* cols, int ncols, int64_t w,
+                          hipStream_t s, SplitWork* sw) {
+    NNGP_REQUIRE(cols != nullptr && ncols >= 0 && w > 0 && w % TB == 0, "potrf_update_cols: bad arguments");
+    const bool h3 = sw != nullptr && sw->planes != nullptr && sw->counters != nullptr && pw == sw->k_cap && po % pw == 0 &&
+                    sw->rows_cap >= n + 256 && NNGP_KNOB(2) != 2 && ld % 4 == 0;
+    H3RegionSpec reg[4];
+    int nreg = 0;
+    const int64_t lead = (po == 0 && pw > 256) ? 64 : 0;
+    auto flush = [&]() -> int {
+        if (nreg == 0) return 0;
+        const int64_t ldp = 4 * sw->k_cap;
+        char* col = sw->planes + (po / pw) * sw->col_stride;  // rows at their global index
+        if (sw->split_panel != po) {
+            NNGP_TRY(launch_split_rows(a + (po + pw) * ld + po, ld, n - po - pw, pw, sw->scale, col + (po + pw) * ldp, ldp, s));
+            sw->split_panel = po;
+        }
+        NNGP_TRY(launch_gemm_nt_h3r(a, ld, col + lead * 4, col + lead * 4, ldp, 0, 1, 0, reg, nreg, pw - lead, -1.0f / (sw->scale * sw->scale),
+                                    1.0f, true, sw->counters, 0, s));
+        for (int r = 0; r < nreg && lead > 0; ++r) {
+            const float* p = a + reg[r].row0 * ld + po;
+            float* c = a + reg[r].row0 * ld + reg[r].col0;
+            NNGP_TRY(launch_gemm_nt_f32(c, ld, p, ld, p, ld, reg[r].n, reg[r].n, lead, -1.0f, 1.0f, true, s));
+            if (reg[r].m > reg[r].n)
+                NNGP_TRY(launch_gemm_nt_f32(c + reg[r].n * ld, ld, p + reg[r].n * ld, ld, p, ld, reg[r].m - reg[r].n, reg[r].n, lead, -1.0f, 1.0f,
+                                            false, s));
+        }
+        nreg = 0;
+        return 0;
+    };
+    for (int i = 0; i < ncols; ++i) {
+        const int64_t o = cols[i];
+        const int64_t wi = (n - o < w) ? n - o : w;
+        NNGP_REQUIRE(o >= po + pw && o % TB == 0 && wi > 0, "potrf_update_cols: bad target column");
+        if (h3 && (n - o) * wi >= 96 * 256 * 256) {
+            reg[nreg++] = H3RegionSpec{o, o, n - o, wi, 0};
+            if (nreg == 4) NNGP_TRY(flush());
+        } else {
+            NNGP_TRY(flush());
+            NNGP_TRY(potrf_update_f32(a, n, ld, po, pw, o, wi, s, sw));
+        }
+    }
+    return flush();
 }
 
 int potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, hipStream_t s) {

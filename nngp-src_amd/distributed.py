@@ -254,8 +254,7 @@ def distributed_factor(model, group=None, nb: int = None):
     if world == 1:
         for k in range(ncols):
             model.factor_panel(k * w, width(k))
-            for j in range(k + 1, ncols):
-                model.factor_update(k * w, width(k), j * w, width(j))
+            model.factor_update_cols(k * w, width(k), [j * w for j in range(k + 1, ncols)], w)
         model.factor_end()
         return model
 
@@ -268,9 +267,8 @@ def distributed_factor(model, group=None, nb: int = None):
             if nxt % world == r:
                 model.factor_update(o, wk, nxt * w, width(nxt))  # column k+1 first: it is on the critical path
             handle = factor_and_send(nxt)
-        for j in owned:
-            if j > nxt:
-                model.factor_update(o, wk, j * w, width(j))
+        # the rest of this rank's block columns: four to a launch (nngp_model_factor_update_cols)
+        model.factor_update_cols(o, wk, [j * w for j in owned if j > nxt], w)
     model.factor_end()
     return model
 

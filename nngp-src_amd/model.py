@@ -108,6 +108,16 @@ class GPModel:
         self._check(self.lib.nngp_model_factor_update(self.handle, int(panel_col0), int(panel_width), int(col0), int(width),
                                                      _lib.stream_ptr()))
 
+    def factor_update_cols(self, panel_col0: int, panel_width: int, cols, width: int):
+        """Apply block column [panel_col0, +panel_width) to several target block columns (first rows / columns ``cols``, ascending):
+        the block columns a rank owns go out four to a split-float16 launch (nngp_model_factor_update_cols)."""
+        cols = [int(c) for c in cols]
+        if not cols:
+            return
+        arr = (ctypes.c_int64 * len(cols))(*cols)
+        self._check(self.lib.nngp_model_factor_update_cols(self.handle, int(panel_col0), int(panel_width), arr, len(cols), int(width),
+                                                          _lib.stream_ptr()))
+
     def factor_end(self):
         self._check(self.lib.nngp_model_factor_end(self.handle, _lib.stream_ptr()))
 

@@ -341,6 +341,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
 int nngp_model_factor_begin(nngp_model* m, void* stream) { (void)m; (void)stream; NOT_HERE("nngp_model_factor_begin"); }
 int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* stream) { (void)m; (void)col0; (void)width; (void)stream; NOT_HERE("nngp_model_factor_panel"); }
 int nngp_model_factor_update(nngp_model* m, int64_t pc, int64_t pw, int64_t c0, int64_t w, void* stream) { (void)m; (void)pc; (void)pw; (void)c0; (void)w; (void)stream; NOT_HERE("nngp_model_factor_update"); }
+int nngp_model_factor_update_cols(nngp_model* m, int64_t panel_col0, int64_t panel_width, const int64_t* cols, int32_t ncols, int64_t width, void* stream) { (void)m; (void)panel_col0; (void)panel_width; (void)cols; (void)ncols; (void)width; (void)stream; NOT_HERE("nngp_model_factor_update_cols"); }
 int nngp_model_factor_end(nngp_model* m, void* stream) { (void)m; (void)stream; NOT_HERE("nngp_model_factor_end"); }
 int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv) { (void)m; (void)a32; (void)ld; (void)dinv; NOT_HERE("nngp_model_factor_buffers"); }
 int nngp_model_prepare_serving(nngp_model* m, void* stream) { (void)m; (void)stream; NOT_HERE("nngp_model_prepare_serving"); }

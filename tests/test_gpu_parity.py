@@ -483,17 +483,19 @@ def test_lookahead_cholesky_matches_recursion():
     assert np.abs(Krows @ alphas[0] + reg * alphas[0][rows] - y[rows]).max() < 1e-7 * np.abs(y).max()
 
 
-def test_right_looking_block_columns_single_rank():
-    """The block-column pieces (factor_panel / factor_update) that the multi-GPU Cholesky deals out, run on one rank."""
+@pytest.mark.parametrize("n,nb", [(3000, 512), (9300, 1024)])
+def test_right_looking_block_columns_single_rank(n, nb):
+    """The block-column pieces (factor_panel / factor_update_cols) that the multi-GPU Cholesky deals out, run on one rank.  The larger
+    case takes the fused float16-pipe panel solve and the multi-region split-float16 updates (four target block columns per launch)."""
     from nngp_src_amd import distributed
-    n, d = 3000, 32
+    d = 32
     x, y = synth.synthetic_queries(n, d, seed=7)
     a = o.make_arch(1)
     ref = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3).fit(x, y)
     model = GPModel(n, d, a.w_std, a.b_std, diag_reg=1e-3)
     model.set_train(x, y)
     model.build_rows(0, n)
-    distributed.distributed_factor(model, nb=512)
+    distributed.distributed_factor(model, nb=nb)
     model.solve()
     info = model.info()
     assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
