@@ -323,7 +323,7 @@ def main():
             distributed.allgather_rows(buf, n, comm=comm)
         e3 = ev()
         if sharded and dist_chol:
-            distributed.distributed_factor(model)  # block columns dealt cyclically, one broadcast per column
+            distributed.distributed_factor(model, comm=comm)  # block columns dealt cyclically, one broadcast per column (nngp_bcast with the library's communicator)
         else:
             model.factor()
         e4 = ev()
@@ -388,7 +388,7 @@ def main():
                         "allgather_GBps_per_rank": round(recv_bytes / 1e9 / (st["allgather"] * 1e-3), 1) if st["allgather"] > 0 else None,
                         "replicated_full_build_ms": None, "replicate_layout_ms_per_step": None,
                         "ranks_seen": ranks_seen, "collective": collective,
-                        "cholesky": "1-D block-cyclic, one broadcast per 1024-wide block column" if dist_chol else "replicated on every rank"}
+                        "cholesky": ("1-D block-cyclic, one broadcast per 1024-wide block column (%s)" % ("nngp_bcast on a side stream" if comm is not None and os.environ.get("NNGP_BCAST", "native") == "native" else "torch.distributed broadcast")) if dist_chol else "replicated on every rank"}
         if not args.no_compare:
             model.set_train(xd, yd)
             ts = []

@@ -205,7 +205,35 @@ def _broadcast(t, src, group=None, async_op=False):
     return work if async_op else _Done()
 
 
-def distributed_factor(model, group=None, nb: int = None):
+class _NativeBcast:
+    """Panel broadcasts through the library's own RCCL communicator (``nngp_bcast``) on a side stream: the transfer of block
+    column k+1 over xGMI runs beside the trailing updates of block column k on the compute stream.  ``wait()`` makes the
+    compute stream wait for the transfer (stream-ordered: no host synchronisation)."""
+
+    def __init__(self, comm):
+        import torch
+        self.comm, self.torch = comm, torch
+        self.stream = torch.cuda.Stream()
+
+    def start(self, buf, src):
+        t = self.torch
+        ready = t.cuda.Event()
+        ready.record(t.cuda.current_stream())       # the owner's pack copies (and every rank's last use of this staging buffer)
+        self.stream.wait_event(ready)
+        with t.cuda.stream(self.stream):
+            self.comm.bcast(buf, src)               # ncclBroadcast in place on the side stream
+            done = t.cuda.Event()
+            done.record(self.stream)
+        outer = self
+
+        class _Handle:
+            def wait(self_inner):
+                outer.torch.cuda.current_stream().wait_event(done)
+                return True
+        return _Handle()
+
+
+def distributed_factor(model, group=None, nb: int = None, comm: "NativeComm" = None):
     """Right-looking float32 Cholesky with the block columns dealt cyclically to the ranks (SURVEY.md 8f row N4, 1-D form).
 
     Every rank keeps a full copy of the factor buffer.  Block column k is final on its owner (k mod world) once the
@@ -217,6 +245,8 @@ def distributed_factor(model, group=None, nb: int = None):
     Look-ahead: after receiving column k, the owner of column k+1 updates and factors THAT column first and starts
     its broadcast; all ranks post the (asynchronous) receive before applying column k to the rest of their columns,
     so the transfer of column k+1 over xGMI overlaps with the trailing updates of column k.
+    ``comm``: the library's RCCL communicator (``NativeComm``): the broadcasts then go through ``nngp_bcast`` on a side
+    stream instead of ``torch.distributed``.
     """
     import torch
     world, r = world_size(), rank()
@@ -228,6 +258,9 @@ def distributed_factor(model, group=None, nb: int = None):
     owned = [j for j in range(ncols) if j % world == r]
     width = lambda j: min(w, np_ - j * w)
     stages = [torch.empty(((np_ * w) + w * 128,), dtype=torch.float32, device=a32.device) for _ in range(2)] if world > 1 else None
+    # with the library's own communicator the panels travel by nngp_bcast (NNGP_BCAST=torch: torch.distributed's broadcast)
+    import os
+    native = _NativeBcast(comm) if (comm is not None and world > 1 and os.environ.get("NNGP_BCAST", "native") == "native") else None
 
     def views(k):
         o, wk = k * w, width(k)
@@ -242,6 +275,8 @@ def distributed_factor(model, group=None, nb: int = None):
             model.factor_panel(o, wk)
             pan.copy_(a32[o:, o:o + wk])
             inv.copy_(dinv[o // 128:(o + wk) // 128])
+        if native is not None:
+            return native.start(buf, k % world)
         return _broadcast(buf, k % world, group, async_op=True)
 
     def receive(k, handle):
@@ -305,7 +340,7 @@ def sharded_fit(model, x, y, group=None, timings=None, distributed_cholesky=True
         allgather_rows(buf, n, group, comm)
     t2 = ev()
     if world > 1 and distributed_cholesky:
-        distributed_factor(model, group)
+        distributed_factor(model, group, comm=comm)
         # float32 breakdown (clamped pivots on any rank's block columns: cond(K + reg I) * eps32 >> 1): every rank holds
         # the whole float64 kernel, so all of them redo the factor on their own GPU, where nngp_model_factor raises the
         # preconditioner shift until the factorisation goes through (one 4-byte status reduction per fit)

@@ -109,6 +109,15 @@ def test_native_rccl_communicator_single_rank():
     assert torch.equal(k, before) and torch.equal(v, torch.arange(33, dtype=torch.float32, device="cuda"))
     lib = _lib.load()
     assert lib.nngp_bcast(_lib.ptr(v), 33, _lib.DTYPE_F32, 3, comm.handle, None) != 0  # root outside the communicator
+    # the panel-broadcast plumbing of the block-cyclic Cholesky: nngp_bcast on a side stream, the compute stream waits by event
+    nb = distributed._NativeBcast(comm)
+    big = torch.randn(1 << 20, dtype=torch.float32, device="cuda")
+    keep = big.clone()
+    handle = nb.start(big, 0)
+    handle.wait()
+    out = big * 2.0  # ordered behind the transfer on the compute stream
+    torch.cuda.synchronize()
+    assert torch.equal(big, keep) and torch.equal(out, keep * 2.0)
     comm.close()
 
 
