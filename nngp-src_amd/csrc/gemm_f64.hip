@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64(double* C, int64_t ldc, 
         if (t0 + len < t1) t1 = t0 + len;
     }
     const double* Ab = A + (int64_t)bi * DBM * lda;
-    const double* Bb = B + (int64_t)bj * DBN * ldb;
+    const double* Bb = B + (int64_t)((xcd_order & 2) ? (bj & 7) : bj) * DBN * ldb;  // (bit 1: timing diagnostic, B aliased to 8 panels: cache-hot operands, wrong result)
 
     f64x2 ga[4], gb[4];
     const int ld_row = tid >> 3, ld_ch = tid & 7;
@@ -195,7 +195,7 @@ int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin,
     }
     if (ksplit <= 1) {
         hipLaunchKernelGGL(k_gemm_nt_f64, dim3((unsigned)(tm * tn)), dim3(256), 0, s, c, ldc, cin ? cin : c, ldcin ? ldcin : ldc,
-                           a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, 1, nullptr, 0, NNGP_KNOB(5) != 8);
+                           a, lda, b, ldb, (int)tm, (int)(k / DBK), alpha, beta, kmode, (int)tn, 1, nullptr, 0, (NNGP_KNOB(5) != 8 ? 1 : 0) | (NNGP_KNOB(5) == 7 ? 2 : 0));
         NNGP_HIP_CHECK(hipGetLastError());
         return 0;
     }
