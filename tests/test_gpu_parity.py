@@ -227,6 +227,36 @@ def test_gemm_split_f16_agrees_with_f32_mfma_in_the_cholesky():
     assert d < 1e-8, d  # alpha is the float64 CG answer either way
 
 
+@pytest.mark.parametrize("n", [9300, 12800])
+def test_grouped_cholesky_matches_the_one_column_form(n):
+    """Round 3's grouped look-ahead Cholesky (block columns in groups of 4: K = 1024 updates inside a group, ONE K = 4096 pass over
+    the columns beyond it, issued as multi-region multi-panel split-float16 launches) against the same factorisation with one
+    block column per group (debug key 2 = 11, the round-2 schedule): both are float32 factors of the same matrix -- the float64
+    CG answer alpha agrees to 1e-9, neither clamps a pivot, the CG takes the same number of iterations (+-1), and two runs of
+    the grouped form give the same bits (the multi-region launches pull tiles from shared counters in any order; the result
+    must not depend on it)."""
+    from nngp_src_amd import _lib
+    x, y = synth.synthetic_queries(n, 48, seed=31)
+    lib = _lib.load(knobs=True)
+    res = {}
+    for key2 in (11, 0, 0):
+        lib.nngp_debug_set(2, key2)
+        try:
+            mdl = GPModel(n, 48, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+            a32, _ = mdl.factor_buffers()
+            res.setdefault(key2, []).append((mdl.info(), mdl.alpha().cpu().numpy().copy(), torch.tril(a32[:n, :n]).clone()))
+            mdl.close()
+        finally:
+            lib.nngp_debug_set(2, 0)
+    (i1, a1, l1), (i4, a4, l4), (_, a4b, l4b) = res[11][0], res[0][0], res[0][1]
+    assert i1["clamped_pivots"] == 0 and i4["clamped_pivots"] == 0 and i4["rel_residual"] < 1e-9
+    assert abs(i1["refine_iters"] - i4["refine_iters"]) <= 1, (i1, i4)
+    assert np.linalg.norm(a1 - a4) <= 1e-9 * np.linalg.norm(a1)
+    assert torch.equal(l4, l4b) and np.array_equal(a4, a4b)
+    # the two factors are float32 factors of one matrix: they differ by rounding only
+    assert (l1 - l4).abs().max().item() <= 2e-3 * l1.abs().max().item()
+
+
 @pytest.mark.parametrize("rows", [128, 512, 24576 + 128])  # 64x128 and 128x128 workgroup tiles
 def test_gemm_in_place_inverse_block(rows):
     torch.manual_seed(2)
