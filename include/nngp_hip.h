@@ -188,7 +188,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
  *   L > 2  L-1 sweeps + the second-order formula                                     2e-10 at L = 3
  * Levels >= 1 are adaptive: the sweeps contract by the spectral radius of I - M^-1 A (M = the float32 factor), which
  * approaches 1 when cond(K + reg I) * eps32 does (small diag_reg, low-dimensional encodings).  After the fixed sweeps
- * predict checks the signs of that -- the alpha solve took >= 8 CG iterations (the default diag level: >= 7; NTK: >= 6, or
+ * predict checks the signs of that -- the alpha solve took >= 7 CG iterations (level >= 2 diag: >= 8; NTK: >= 6, or
  * the two sweeps' own estimate of what they left exceeds 3e-7, see nngp_model_sweep_estimate), or a row's first-order term
  * z.r is too large for its second-order error to be small (a loose lower bound: the backstop when the alpha solve says
  * nothing, e.g. y = 0) -- and then continues the rows by preconditioned

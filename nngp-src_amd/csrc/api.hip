@@ -1277,7 +1277,9 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         // (NTK: two sweeps leave ~rho^3 where the NNGP formula leaves ~rho^4: 6 iterations ~ 2e-4, 5 ~ 6e-6, 4 ~ 4e-8 -- the
         // threshold was 4 until round 2, which sent the N = 16384 bench config (4 iterations, 3.6e-8 after the sweeps) through
         // three continuation steps, 78 ms per predict instead of 37)
-        bool weak = m->iters >= (is_ntk ? 6 : (check_kind == 4 ? 7 : 8)) || m->reg_fac > m->reg;
+        // (round 3: the full covariance continues from 7 iterations too -- a 7-iteration fit of the large-N sweep, N = 5007, d = 3, left 2.1e-4 in
+        // its diagonal where the diag path, which already continued from 7, was at 8e-9)
+        bool weak = m->iters >= (is_ntk ? 6 : ((check_kind == 4 || check_kind == 2) ? 7 : 8)) || m->reg_fac > m->reg;
         if (!weak && check_kind == 3) {
             // NTK below 6 iterations: the count alone does not separate 4e-8 (N = 16384, d = 256: 4 iterations) from 5e-5
             // (N = 907, d = 2, four layers, diag_reg 1e-4: also 4).  What the two sweeps removed does: 16-byte read-back.
