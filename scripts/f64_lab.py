@@ -14,7 +14,7 @@ b = torch.randn((n, n), dtype=torch.float64, device=dev)
 c = torch.zeros((m, n), dtype=torch.float64, device=dev)
 res = {}
 for rnd in range(4):
-    for v in [int(x) for x in os.environ.get("F64_VARIANTS", "0,7,8").split(",")]:
+    for v in [int(x) for x in os.environ.get("F64_VARIANTS", "0,6").split(",")]:
         _lib.check(lib.nngp_debug_set(5, v))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -297,6 +297,27 @@ def test_gemm_f64_mfma():
     G.gemm_nt_f64(c1, None, a, b, 1.0, 0.0)
     G.gemm_nt_f64(c2, None, a, b, 1.0, 0.0)
     assert torch.equal(c1, c2) and (c1 - a @ b.T).abs().max().item() < 1e-10
+    # large products (enough tiles that no split K is taken; an odd multiple of 128 rows): exact on integers (asymmetric operands,
+    # A = I catches lane-map and tile-index mistakes), in place with beta, and the same bits on every run
+    m, n, k = 640, 33 * 128, 208
+    a = torch.randint(-8, 9, (m, k), device=G.dev()).double(); b = torch.randint(-8, 9, (n, k), device=G.dev()).double()
+    cin = torch.randint(-8, 9, (m, n), device=G.dev()).double()
+    c = cin.clone()
+    G.gemm_nt_f64(c, c, a, b, -1.0, 3.0)
+    assert torch.equal(c, 3.0 * cin - a @ b.T)
+    eye = torch.zeros((640, 640), dtype=torch.float64, device=G.dev()); eye.fill_diagonal_(1.0)
+    bb = torch.randn((33 * 128, 640), dtype=torch.float64, device=G.dev())
+    c = torch.full((640, 33 * 128), float("nan"), dtype=torch.float64, device=G.dev())
+    G.gemm_nt_f64(c, None, eye, bb, 1.0, 0.0)
+    assert torch.equal(c, bb.T.contiguous())
+    a = torch.randn((1024, 4096 + 16), dtype=torch.float64, device=G.dev()); b = torch.randn((4224, 4096 + 16), dtype=torch.float64, device=G.dev())
+    outs = []
+    for _ in range(3):
+        c = torch.empty((1024, 4224), dtype=torch.float64, device=G.dev())
+        G.gemm_nt_f64(c, None, a, b, 1.0, 0.0)
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[0] - a @ b.T).abs().max().item() < 1e-10
 
 
 # ---------------------------------------------------------------------------- Cholesky / TRSM
