@@ -267,6 +267,15 @@ int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const fl
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                      const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                      void* stream);
+/* The same float64 product in float64 GRADE on the int8 matrix pipe (gemm_i8s.hip): every row of A and of B is scaled by its own
+ * power of two and cut into `slices_a` / `slices_b` exact balanced 8-bit digit planes; the plane pairs with ia + ib <= cut are
+ * multiplied exactly (int32 accumulation) and combined in float64.  Error: ~256^-(cut+2) and 256^-slices of (row maximum of A) x
+ * (row maximum of B) x K per entry -- with 5 x 5 planes and cut = 4, about 2^-40 of that bound.  This is the residual product of the
+ * posterior (reference: predict_fn(..., compute_cov=True), train.py:157-158) as a test / integration primitive: it allocates and
+ * frees its own planes.  M, N multiples of 128, any K >= 1; lda, ldb even; 2 <= slices <= 6.  Cin may be C or NULL (beta = 0). */
+int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
+                     const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                     int32_t slices_a, int32_t slices_b, int32_t cut, void* stream);
 /* y = (A + diag_add I) x for a symmetric n x n float64 matrix stored in full (leading dimension lda), read from its LOWER
  * triangle only: the product of the alpha CG (half the bytes of a plain GEMV, fixed summation order).  Any n >= 1; what
  * lies beyond row / column n in a padded buffer is never read. */

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode", "nngp_comm_unique_id", "nngp_comm_create", "nngp_comm_destroy", "nngp_comm_library",
     "nngp_allgather_rows", "nngp_bcast", "nngp_model_update_timer", "nngp_model_update_timer_read", "nngp_symv_f64",
-    "nngp_pool_select", "nngp_model_update_timer_bytes", "nngp_model_factor_update_cols",
+    "nngp_pool_select", "nngp_model_update_timer_bytes", "nngp_model_factor_update_cols", "nngp_gemm_nt_i8s",
 )
 
 
@@ -116,6 +116,7 @@ def bind_prototypes(lib, knobs: bool = False):
     lib.nngp_model_sweep_estimate.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     lib.nngp_model_append.argtypes = [vp, vp, vp, i64, vp]
     lib.nngp_gemm_nt_f64.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, vp]
+    lib.nngp_gemm_nt_i8s.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, dbl, dbl, i32, i32, i32, vp]
     lib.nngp_potrf_f32.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.nngp_gemm_nt_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float, i32, vp]
     lib.nngp_gemm_nt_h3.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_float,

@@ -115,6 +115,10 @@ struct nngp_model {
     double* ktd_aux = nullptr;   // [ktd rows, np_cap] NNGP cross kernel when get == ntk
     int64_t ktd_aux_cap = 0;
 
+    // Sliced int8 copies of K for the residual products of the covariance (gemm_i8s.hip): allocated and cut by the first predict
+    // that takes that path, cut again after every change of K.
+    I8Work i8{};
+
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
     // Diagonal shift of the float32 factor's input.  = reg, unless the float32 factorisation of K + reg I broke down
     // (pivots at the rounding-noise floor: cond * eps32 >> 1); nngp_model_factor then factors K + reg_fac I with a
@@ -153,6 +157,7 @@ struct nngp_model {
         if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
+        dev_free(i8.kplanes); dev_free(i8.kscale); dev_free(i8.zplanes); dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
@@ -303,6 +308,83 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
     return 0;
 }
 
+
+// ---- float64-grade residual products on the int8 matrix pipe (gemm_i8s.hip) ----
+constexpr int64_t kI8RowBlock = 2048;  // right-hand-side rows per pass (bounds the int32 partial buffer)
+
+// Worth it from a few thousand training rows and two 128-row tiles of right-hand sides on (256 x 256 tiles; below that the float64
+// GEMM's 128 x 128 tiles fill the chip better).  Debug key 5 = 50: float64 matrix pipe instead.
+bool use_i8s(const nngp_model* m, int64_t mp) { return m->np >= 4096 && mp >= 256 && NNGP_KNOB(5) != 50; }
+
+int ensure_i8s(nngp_model* m, int64_t mp) {
+    I8Work& w = m->i8;
+    if (NNGP_KNOB(5) == 51) { w.ns_k = w.ns_z = 4; w.cut = 3; }
+    else if (NNGP_KNOB(5) == 52) { w.ns_k = w.ns_z = 6; w.cut = 5; }
+    else { w.ns_k = w.ns_z = 5; w.cut = 4; }
+    if (w.kplanes == nullptr) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        w.k_rows = round_up(m->np_cap, 256);
+        NNGP_TRY(dev_alloc(&w.kplanes, 6 * w.k_rows * m->np_cap));
+        NNGP_TRY(dev_alloc(&w.kscale, m->np_cap));
+        NNGP_TRY(dev_alloc(&w.counters, 16));
+        NNGP_HIP_CHECK(hipMemset(w.counters, 0, 16 * sizeof(int)));
+        NNGP_HIP_CHECK(hipMemset(w.kplanes, 0, (size_t)(6 * w.k_rows * m->np_cap)));
+        w.k_ready = false;
+    }
+    const int64_t rows = mp < kI8RowBlock ? mp : kI8RowBlock;
+    if (rows > w.z_rows) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
+        NNGP_TRY(dev_alloc(&w.zplanes, 6 * (rows + 256) * m->np_cap));
+        NNGP_TRY(dev_alloc(&w.zscale, rows));
+        NNGP_TRY(dev_alloc(&w.partial, i8s_chunks(m->np_cap) * 8 * rows * m->np_cap));
+        NNGP_HIP_CHECK(hipMemset(w.zplanes, 0, (size_t)(6 * (rows + 256) * m->np_cap)));
+        w.z_rows = rows;
+    }
+    return 0;
+}
+
+// the digit planes of the float64 kernel (whole matrix, rows scaled by their maxima)
+int slice_k_planes(nngp_model* m, hipStream_t s) {
+    I8Work& w = m->i8;
+    // K is a kernel matrix (positive semi-definite): row i is bounded by sqrt(K_ii max_j K_jj) -- no pass over the matrix for the scales
+    NNGP_TRY(launch_i8s_diag_bound_scale(m->k64, m->ld, m->np, w.kscale, s));
+    NNGP_TRY(launch_i8s_slice_rows(m->k64, m->ld, m->np, m->np, w.ns_k, w.kscale, nullptr, w.kplanes, m->np_cap, w.k_rows * m->np_cap, s));
+    w.k_ns_done = w.ns_k;
+    w.k_ready = true;
+    return 0;
+}
+
+// out [mp, np] = rhs - z (K + reg I) for z = z64 (or another [mp, np] block), float64 grade
+int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s) {
+    const int64_t np = m->np;
+    if (!use_i8s(m, mp)) {
+        NNGP_TRY(launch_gemm_nt_f64(out, np, rhs, np, z, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
+        return launch_axpby_mat(out, 1.0, z, -m->reg, np, mp, np, s);
+    }
+    NNGP_TRY(ensure_i8s(m, mp));
+    I8Work& w = m->i8;
+    // The planes of K are cut by the first residual product after a fit, in stream order: 13 N^2 bytes of HBM traffic (2.7 ms at
+    // N = 32768).  Measured and dropped (scripts/i8s_ab.py, round 3): slicing beside the factorisation on a second stream costs the
+    // Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768 small
+    // workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on a
+    // CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
+    if (!w.k_ready || w.k_ns_done != w.ns_k) NNGP_TRY(slice_k_planes(m, s));
+    I8Plan pl;
+    NNGP_TRY(i8s_plan(w.ns_z, w.ns_k, w.cut, &pl));
+    const int64_t nchunk = i8s_chunks(np);
+    for (int64_t r0 = 0; r0 < mp; r0 += kI8RowBlock) {
+        const int64_t mb = mp - r0 < kI8RowBlock ? mp - r0 : kI8RowBlock;
+        const int64_t slab = mb * np;
+        NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, w.ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
+        NNGP_TRY(launch_gemm_nt_i8s(w.partial, np, slab, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, w.kplanes, m->np_cap,
+                                    w.k_rows * m->np_cap, pl, mb, np, np, w.counters, 0, s));
+        NNGP_TRY(launch_i8s_combine(out + r0 * np, np, rhs + r0 * np, np, 1.0, -1.0, z + r0 * np, np, -m->reg, w.partial, np, slab,
+                                    (int)nchunk, pl.ndiag, w.zscale, w.kscale, mb, np, s));
+    }
+    return 0;
+}
+
 // the factor has float16-split copies (look-ahead factorisation) and the caller did not ask for the float32 path
 // and the block of right-hand sides is large enough for the 256-row tiles of the float16 GEMM to pay (measured, ms per
 // diag-variance call at level 2, float16 / float32 solves -- N = 10800: M = 128: 6.5 / 5.6, 512: 9.1 / 8.8, 1024: 11.5 / 12.9;
@@ -362,8 +444,7 @@ int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps,
     NNGP_TRY(apply_inverse_f32(m, mp, s));
     NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));
     for (int it = 0; it < sweeps + (final_residual ? 1 : 0); ++it) {
-        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, rhs, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
-        NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+        NNGP_TRY(residual_rows(m, m->r64, rhs, m->z64, mp, s));
         if (it == sweeps) break;
         NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
         NNGP_TRY(apply_inverse_f32(m, mp, s));
@@ -619,6 +700,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     a.ld64 = a.ld32 = m->ld;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
     m->a32_built = false;
+    m->i8.k_ready = false;
     if (a.sym) {  // whole matrix in one build: the float32 factorisation input falls out of the same epilogue
         if (m->get == NNGP_GET_NNGP) { a.nngp32 = m->a32; a.diag_add_nngp32 = m->reg; }
         else { a.ntk32 = m->a32; a.diag_add_ntk32 = m->reg; }
@@ -767,6 +849,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     m->solved = false;
     m->solve_pending = false;
     m->serving_ready = false;
+    m->i8.k_ready = false;
     // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
@@ -1135,13 +1218,11 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         if (!serving) return refined_solve_rows(m, ktd, mp, sweeps, final_residual, s);
         NNGP_TRY(launch_gemm_nt_f64(m->z64, np, nullptr, 0, ktd, np, m->ainv64, np, mp, np, np, 1.0, 0.0, s));
         if (m->serving_weak) {  // ill-conditioned fit: X is less accurate; one correction step with X as the solver
-            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
-            NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+            NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s));
             NNGP_TRY(launch_gemm_nt_f64(m->z64, np, m->z64, np, m->r64, np, m->ainv64, np, mp, np, np, 1.0, 1.0, s));
         }
         if (final_residual) {
-            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
-            NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+            NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s));
         }
         return 0;
     };
@@ -1302,8 +1383,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             } else if (check_kind == 4) {
                 // level 1: r64 is the residual of z64 already
             } else {
-                NNGP_TRY(launch_gemm_nt_f64(m->r64, np, ktd, np, m->z64, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
-                NNGP_TRY(launch_axpby_mat(m->r64, 1.0, m->z64, -m->reg, np, mp, np, s));
+                NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s));
             }
             if (check_kind == 3)  // tolerance from what the second sweep did to the variance (rows.tol holds z . k)
                 NNGP_TRY(launch_rows_prepare_ntk(m->rows.delta, m->rows.coef, m->rows.tol, var_or_cov, full ? mt + 1 : 1, mt,
@@ -1373,6 +1453,44 @@ int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
                      void* stream) {
     NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr, "gemm_nt_f64: NULL argument");
     return launch_gemm_nt_f64(c, ldc, cin, ldcin, a, lda, b, ldb, m, n, k, alpha, beta, (hipStream_t)stream);
+}
+
+int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda, const double* b,
+                     int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, int32_t slices_a, int32_t slices_b,
+                     int32_t cut, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(a != nullptr && b != nullptr && c != nullptr && m > 0 && n > 0 && k > 0 && m % TB == 0 && n % TB == 0 && ldc >= n &&
+                     lda >= k && ldb >= k,
+                 "gemm_nt_i8s: m, n must be multiples of %d", TB);
+    I8Plan pl;
+    NNGP_TRY(i8s_plan(slices_a, slices_b, cut, &pl));
+    const int64_t mp = round_up(m, 256), np = round_up(n, 256), kp = round_up(k, 128);
+    const int64_t nchunk = i8s_chunks(k);
+    const int64_t slab = m * n;
+    const size_t plane_bytes = (size_t)((mp * slices_a + np * slices_b) * kp);
+    const size_t part_bytes = (size_t)(nchunk * pl.ndiag * slab) * sizeof(int32_t);
+    NNGP_REQUIRE(part_bytes < (size_t)16 << 30, "gemm_nt_i8s: the test entry keeps all partial products (16 GB limit)");
+    char* ws = nullptr;
+    NNGP_HIP_CHECK(hipMalloc((void**)&ws, plane_bytes + part_bytes + sizeof(double) * (size_t)(m + n) + 64));
+    NNGP_HIP_CHECK(hipMemsetAsync(ws, 0, plane_bytes, s));
+    int8_t* pa = reinterpret_cast<int8_t*>(ws);
+    int8_t* pb = pa + mp * slices_a * kp;
+    int32_t* part = reinterpret_cast<int32_t*>(ws + plane_bytes);
+    double* sca = reinterpret_cast<double*>(ws + plane_bytes + part_bytes);
+    double* scb = sca + m;
+    int* counters = reinterpret_cast<int*>(scb + n);
+    NNGP_HIP_CHECK(hipMemsetAsync(counters, 0, 64, s));
+    int rc = launch_i8s_slice_rows(a, lda, m, k, slices_a, nullptr, sca, pa, kp, mp * kp, s);
+    if (rc == 0) rc = launch_i8s_slice_rows(b, ldb, n, k, slices_b, nullptr, scb, pb, kp, np * kp, s);
+    if (rc == 0)
+        rc = launch_gemm_nt_i8s(part, n, slab, pa, kp, mp * kp, pb, kp, np * kp, pl, m, n, k, counters,
+                                NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 0, s);
+    if (rc == 0)
+        rc = launch_i8s_combine(c, ldc, cin ? cin : c, cin ? ldcin : ldc, beta, alpha, nullptr, 0, 0.0, part, n, slab, (int)nchunk,
+                                pl.ndiag, sca, scb, m, n, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(ws);
+    return rc;
 }
 
 int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased, uint64_t seed,

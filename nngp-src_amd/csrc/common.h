@@ -192,6 +192,37 @@ int potrf_update_cols_f32(float* a, int64_t n, int64_t ld, int64_t po, int64_t p
 int trsm_rut_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ldl, const float* dinvt, int64_t n,
                  hipStream_t s);
 
+// ---- gemm_i8s.hip: float64-grade products on the int8 matrix pipe (exactly sliced operands) ----
+struct I8Plan {       // which digit-plane pairs are multiplied, grouped by diagonal ia + ib (largest first)
+    int ndiag, npairs;
+    int dstart[9];    // first pair of diagonal dd; dstart[ndiag] = npairs
+    int pa[32], pb[32];
+};
+struct I8Work {       // one per model: digit planes of K and of a block of right-hand-side rows (api.hip)
+    int8_t* kplanes = nullptr;   // [6][k_rows][np_cap]: planes of the float64 kernel, row stride np_cap bytes
+    double* kscale = nullptr;    // [np_cap] row scales
+    int64_t k_rows = 0;
+    bool k_ready = false;        // the planes belong to the current kernel matrix
+    int k_ns_done = 5;           // planes per row they were cut into
+    int8_t* zplanes = nullptr;   // [6][z_rows + 256][np_cap]
+    double* zscale = nullptr;    // [z_rows]
+    int64_t z_rows = 0;
+    int32_t* partial = nullptr;  // [chunks][diagonals][z_rows][np_cap] exact plane products
+    int* counters = nullptr;     // work counters of the persistent grid
+    int ns_k = 5, ns_z = 5, cut = 4;
+};
+int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl);
+int64_t i8s_chunks(int64_t k);  // K chunks (of <= 16384) a product over k columns is cut into
+int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double* scale, hipStream_t s);
+int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t cols, int ns, const double* scale_in, double* scale_out,
+                          int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s);  // scale_in NULL: scale by the row maxima
+int launch_gemm_nt_i8s(int32_t* partial, int64_t ldc, int64_t slab, const int8_t* a, int64_t lda, int64_t sa, const int8_t* b,
+                       int64_t ldb, int64_t sb, const I8Plan& pl, int64_t m, int64_t n, int64_t k, int* counters, int reserve_cus,
+                       hipStream_t s);
+int launch_i8s_combine(double* out, int64_t ldo, const double* cin, int64_t ldcin, double beta, double alpha, const double* g,
+                       int64_t ldg, double gamma, const int32_t* partial, int64_t ldc, int64_t slab, int nchunk, int ndiag,
+                       const double* sa, const double* sb, int64_t rows, int64_t cols, hipStream_t s);
+
 // ---- gemm_f64.hip ----
 int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                        const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,

@@ -352,6 +352,71 @@ int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clampe
 int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n, int64_t k, float alpha, float beta, int32_t lower_only, void* stream) { (void)c; (void)ldc; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)lower_only; (void)stream; NOT_HERE("nngp_gemm_nt_f32"); }
 int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n, int64_t k, float alpha, float beta, float scale, int32_t lower_only, void* stream) { (void)c; (void)ldc; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)scale; (void)lower_only; (void)stream; NOT_HERE("nngp_gemm_nt_h3"); }
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda, const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, void* stream) { (void)c; (void)ldc; (void)cin; (void)ldcin; (void)a; (void)lda; (void)b; (void)ldb; (void)m; (void)n; (void)k; (void)alpha; (void)beta; (void)stream; NOT_HERE("nngp_gemm_nt_f64"); }
+/* The sliced int8 product of csrc/gemm_i8s.hip restated on the host: the same row scales, the same balanced base-256 digits, the
+ * exact integer sums of the plane pairs with ia + ib <= cut, the same float64 Horner combination -- every step is either exact or
+ * one IEEE operation in a fixed order, so the device result is reproduced BIT FOR BIT (tests/test_gpu_parity.py).  O(pairs m n k). */
+static double i8s_row_scale(const double* p, int64_t k) {
+    double mx = 0.0;
+    for (int64_t c = 0; c < k; ++c) mx = fmax(mx, fabs(p[c]));
+    if (!(mx > 0.0 && mx < 1.0e300)) return 1.0;
+    int e = 0;
+    const double f = frexp(mx, &e);
+    return ldexp(1.0, f <= 0.984375 ? e + 1 : e + 2);  /* |x| / scale <= 126/256: top digit <= 126 + carry */
+}
+static void i8s_digits(const double* p, int64_t k, int ns, double scale, int8_t* dig /* [ns][k] */) {
+    const double inv = ldexp(1.0, 8 * ns) / scale;
+    for (int64_t c = 0; c < k; ++c) {
+        long long x = llrint(p[c] * inv);
+        for (int s = ns - 1; s >= 1; --s) {
+            const long long d = ((x + 128) & 255) - 128;
+            x = (x - d) >> 8;
+            dig[(int64_t)s * k + c] = (int8_t)d;
+        }
+        dig[c] = (int8_t)x;
+    }
+}
+__attribute__((optimize("fp-contract=off")))
+int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda, const double* b,
+                     int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, int32_t slices_a, int32_t slices_b,
+                     int32_t cut, void* stream) {
+    (void)stream;
+    REQUIRE(a != NULL && b != NULL && c != NULL && m > 0 && n > 0 && k > 0, "gemm_nt_i8s: bad arguments");
+    REQUIRE(slices_a >= 2 && slices_a <= 6 && slices_b >= 2 && slices_b <= 6 && cut >= 0, "gemm_nt_i8s: 2..6 planes per operand");
+    if (cut > slices_a + slices_b - 2) cut = slices_a + slices_b - 2;
+    int8_t* da = (int8_t*)malloc((size_t)(m * slices_a * k));
+    int8_t* db = (int8_t*)malloc((size_t)(n * slices_b * k));
+    double* sa = (double*)malloc(sizeof(double) * (size_t)(m + n));
+    if (da == NULL || db == NULL || sa == NULL) { free(da); free(db); free(sa); return fail(-2, "gemm_nt_i8s: out of memory"); }
+    double* sb = sa + m;
+    for (int64_t r = 0; r < m; ++r) { sa[r] = i8s_row_scale(a + r * lda, k); i8s_digits(a + r * lda, k, slices_a, sa[r], da + r * slices_a * k); }
+    for (int64_t r = 0; r < n; ++r) { sb[r] = i8s_row_scale(b + r * ldb, k); i8s_digits(b + r * ldb, k, slices_b, sb[r], db + r * slices_b * k); }
+    if (cin == NULL) { cin = c; ldcin = ldc; }
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < m; ++r) {
+        for (int64_t col = 0; col < n; ++col) {
+            double t = 0.0;
+            for (int e = cut; e >= 0; --e) {
+                long long sum = 0;
+                for (int ia = 0; ia < slices_a; ++ia) {
+                    const int ib = e - ia;
+                    if (ib < 0 || ib >= slices_b) continue;
+                    const int8_t* pa = da + (r * slices_a + ia) * k;
+                    const int8_t* pb = db + (col * slices_b + ib) * k;
+                    long long acc = 0;
+                    for (int64_t kk = 0; kk < k; ++kk) acc += (int)pa[kk] * (int)pb[kk];
+                    sum += acc;
+                }
+                t = t * 0.00390625 + (double)sum;
+            }
+            const double w = alpha * sa[r] * (1.0 / 65536.0);
+            double v = w * sb[col] * t;
+            if (beta != 0.0) v += beta * cin[r * ldcin + col];
+            c[r * ldc + col] = v;
+        }
+    }
+    free(da); free(db); free(sa);
+    return 0;
+}
 /* pool scoring: the same keys (counter-based generator) and the same order as the device kernels */
 static uint64_t splitmix64_host(uint64_t seed, uint64_t idx) {
     uint64_t z = (idx + 1ULL) * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;

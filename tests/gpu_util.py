@@ -55,6 +55,16 @@ def gemm_nt_f64(c, cin, a, b, alpha, beta):
     torch.cuda.synchronize()
 
 
+def gemm_nt_i8s(c, cin, a, b, alpha, beta, slices_a=5, slices_b=5, cut=4):
+    lib = _lib.load()
+    m, k = a.shape
+    n = b.shape[0]
+    _lib.check(lib.nngp_gemm_nt_i8s(_lib.ptr(c), c.stride(0), _lib.ptr(cin), 0 if cin is None else cin.stride(0), _lib.ptr(a),
+                                    a.stride(0), _lib.ptr(b), b.stride(0), m, n, k, alpha, beta, slices_a, slices_b, cut,
+                                    _lib.stream_ptr()))
+    torch.cuda.synchronize()
+
+
 def potrf(a):
     """a: [n, n] float32 cuda tensor (lower triangle used); returns (dinv [n/128,128,128], clamped)."""
     lib = _lib.load()

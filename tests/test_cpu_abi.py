@@ -120,3 +120,39 @@ def test_pool_select_host_build_against_numpy():
     sel = c_abi.pool_select(mean, var, m // 2, biased=True, seed=3)
     assert len(set(sel.tolist())) == m // 2 and score[sel].mean() > 1.2 * np.delete(score, sel).mean()
     assert c_abi.lib().nngp_pool_select(None, 5, 1, None, 2, 0, 0, None, None) != 0
+
+
+def _host_gemm_i8s(a, b, cin, alpha, beta, sa, sb, cut):
+    lib = c_abi.lib()
+    m, k = a.shape
+    n = b.shape[0]
+    c = np.full((m, n), np.nan)
+    vp = lambda arr: None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.nngp_gemm_nt_i8s(vp(c), n, vp(cin), 0 if cin is None else cin.shape[1], vp(a), a.shape[1], vp(b), b.shape[1], m, n, k,
+                              alpha, beta, sa, sb, cut, None)
+    assert rc == 0, lib.nngp_last_error()
+    return c
+
+
+def test_host_sliced_int8_product():
+    """The host restatement of csrc/gemm_i8s.hip (the posterior's residual product, train.py:157-158): exact on integers,
+    float64-grade on random rows whose magnitudes spread over 2^18, error falling by ~2^-8 per diagonal."""
+    rng = np.random.default_rng(3)
+    m, n, k = 24, 40, 333
+    a = rng.integers(-30000, 30001, (m, k)).astype(np.float64)
+    b = rng.integers(-30000, 30001, (n, k)).astype(np.float64)
+    c0 = rng.integers(-9, 10, (m, n)).astype(np.float64)
+    got = _host_gemm_i8s(a, b, c0, -1.0, 1.0, 3, 3, 4)   # 3 planes hold 23 bits + sign; all 9 pairs
+    assert np.array_equal(got, c0 - a @ b.T)
+    a = rng.standard_normal((m, k)) * np.exp2(rng.integers(-18, 1, (m, k)))
+    b = rng.standard_normal((n, k)) * np.exp2(rng.integers(-6, 1, (n, 1)))
+    ref = (a.astype(np.longdouble) @ b.astype(np.longdouble).T).astype(np.float64)
+    unit = np.abs(a).max(1)[:, None] * np.abs(b).max(1)[None, :]
+    errs = []
+    for sa, sb, cut in ((3, 3, 2), (4, 4, 3), (5, 5, 4), (6, 6, 5)):
+        got = _host_gemm_i8s(a, b, None, 1.0, 0.0, sa, sb, cut)
+        errs.append(np.max(np.abs(got - ref) / unit))
+    # dropped pairs: weight 256^-(cut+3), ~cut+2 of them, each a sum of k products of two digits (<= 2^14); scale^2 <= 16 unit
+    for (cut, e) in zip((2, 3, 4, 5), errs):
+        assert e < (cut + 2) * np.sqrt(k) * 2.0 ** 14 * 256.0 ** -(cut + 3) * 16, (cut, e)
+    assert errs[2] < 1e-9 and errs[3] < 1e-11

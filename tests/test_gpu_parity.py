@@ -204,6 +204,94 @@ def test_gemm_split_f16_random(m, n, k):
         assert torch.all(c[tile_upper] == 0)
 
 
+def test_gemm_sliced_int8_exact_on_integers():
+    """Sliced int8 product (csrc/gemm_i8s.hip; the posterior's residual product, train.py:157-158): with A = I against an
+    asymmetric B and with integer operands below 2^23 (three 8-bit planes, all nine pairs) every step is exact -- catches
+    lane-map, digit and tile-index mistakes.  Edge tiles (m, n not multiples of 256), k not a multiple of 128."""
+    torch.manual_seed(21)
+    m, n, k = 384, 640, 200
+    b = torch.randint(-30000, 30001, (n, k), device=G.dev()).double()
+    a = torch.zeros((m, k), device=G.dev(), dtype=torch.float64)
+    a[torch.arange(200), torch.arange(200)] = 1.0
+    c = torch.full((m, n), float("nan"), device=G.dev(), dtype=torch.float64)
+    G.gemm_nt_i8s(c, None, a, b, 1.0, 0.0, 3, 3, 4)
+    assert torch.equal(c[:200], b[:, :200].T.contiguous()) and torch.all(c[200:] == 0)
+    a = torch.randint(-30000, 30001, (m, k), device=G.dev()).double()
+    c0 = torch.randint(-8, 9, (m, n), device=G.dev()).double()
+    c = torch.full_like(c0, float("nan"))
+    G.gemm_nt_i8s(c, c0, a, b, -1.0, 1.0, 3, 3, 4)
+    assert torch.equal(c, c0 - a @ b.T)
+
+
+def test_gemm_sliced_int8_is_the_host_restatement_bit_for_bit():
+    """Every step of the sliced product is exact or one IEEE operation in a fixed order: the host restatement
+    (oracle/nngp_cpu_abi.c) reproduces the device result bit for bit, on rows whose magnitudes spread over 2^18."""
+    from oracle import c_abi
+    import ctypes
+    rng = np.random.default_rng(8)
+    m, n, k = 256, 384, 700
+    a = rng.standard_normal((m, k)) * np.exp2(rng.integers(-18, 1, (m, k)))
+    b = rng.standard_normal((n, k)) * np.exp2(rng.integers(-6, 1, (n, 1)))
+    c0 = rng.standard_normal((m, n))
+    host = np.full((m, n), np.nan)
+    lib = c_abi.lib()
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+    for sa, sb, cut in ((5, 5, 4), (4, 6, 3), (6, 6, 5)):
+        assert lib.nngp_gemm_nt_i8s(vp(host), n, vp(c0), n, vp(a), k, vp(b), k, m, n, k, -1.0, 1.0, sa, sb, cut, None) == 0
+        c = torch.full((m, n), float("nan"), device=G.dev(), dtype=torch.float64)
+        G.gemm_nt_i8s(c, torch.from_numpy(c0).to(G.dev()), torch.from_numpy(a).to(G.dev()), torch.from_numpy(b).to(G.dev()),
+                      -1.0, 1.0, sa, sb, cut)
+        assert np.array_equal(c.cpu().numpy(), host), (sa, sb, cut, np.abs(c.cpu().numpy() - host).max())
+    ref = c0 - (a.astype(np.longdouble) @ b.astype(np.longdouble).T).astype(np.float64)
+    unit = np.abs(a).max(1)[:, None] * np.abs(b).max(1)[None, :]
+    assert np.max(np.abs(host - ref) / unit) < 1e-11   # 6 x 6 planes, cut 5
+
+
+def test_gemm_sliced_int8_k_chunks_cannot_overflow():
+    """K beyond one 16384-chunk on the worst case the digits allow: every entry of a row equal (top digit 126 or 127), the lower
+    digits -128 or 127 by choice of the value, all products of one sign -- the int32 accumulators hold up to 2^30.9 per chunk.
+    The host restatement sums in int64: equality means no accumulator wrapped."""
+    from oracle import c_abi
+    import ctypes
+    m, n, k = 128, 256, 2 * 16384 + 640
+    lib = c_abi.lib()
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+    for digits in ((126, -128, -128, -128, -128), (125, 127, 127, 127, 127)):
+        # every entry = -(sum digits 256^-(i+1)) of the row scale 1 (row maximum 0.49.. = f 2^-1 with f <= 126/128)
+        frac = sum(d * 256.0 ** -(i + 1) for i, d in enumerate(digits))
+        a = np.full((m, k), -frac)
+        b = np.full((n, k), -frac)
+        b[5] *= 0.5
+        host = np.full((1, 8), np.nan)
+        assert lib.nngp_gemm_nt_i8s(vp(host), 8, None, 0, vp(a[:1].copy()), k, vp(b[:8].copy()), k, 1, 8, k, 1.0, 0.0, 5, 5, 4, None) == 0
+        c = torch.full((m, n), float("nan"), device=G.dev(), dtype=torch.float64)
+        G.gemm_nt_i8s(c, None, torch.from_numpy(a).to(G.dev()), torch.from_numpy(b).to(G.dev()), 1.0, 0.0, 5, 5, 4)
+        got = c.cpu().numpy()
+        assert np.all(got[:, np.arange(n) != 5] == host[0, 0]) and np.all(got[:, 5] == host[0, 5])
+        assert abs(host[0, 0] - (a[0] @ b[0])) < 1e-9 * abs(a[0] @ b[0])
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (1024, 1280, 4096), (512, 2304, 20000)])
+def test_gemm_sliced_int8_random(m, n, k):
+    """Float64-grade accuracy of 5 x 5 planes with cut 4 against an 80-bit product, relative to the row maxima."""
+    rng = np.random.default_rng(m + k)
+    a = rng.standard_normal((m, k)) * np.exp2(rng.integers(-12, 1, (m, k)))
+    b = rng.standard_normal((n, k)) * np.exp2(rng.integers(-6, 1, (n, 1)))
+    at, bt = torch.from_numpy(a).to(G.dev()), torch.from_numpy(b).to(G.dev())
+    c = torch.full((m, n), float("nan"), device=G.dev(), dtype=torch.float64)
+    G.gemm_nt_i8s(c, None, at, bt, 1.0, 0.0)
+    rows = rng.choice(m, 24, replace=False)
+    ref = (a[rows].astype(np.longdouble) @ b.astype(np.longdouble).T).astype(np.float64)
+    unit = np.abs(a[rows]).max(1)[:, None] * np.abs(b).max(1)[None, :]
+    err = np.max(np.abs(c.cpu().numpy()[rows] - ref) / unit)
+    assert err < 6 * np.sqrt(k) * 2.0 ** 14 * 256.0 ** -7 * 16, err   # six dropped pairs of weight 256^-7; scale^2 <= 16 unit
+    # and against the float64 matrix pipe on the whole product
+    c64 = torch.full_like(c, float("nan"))
+    G.gemm_nt_f64(c64, None, at, bt, 1.0, 0.0) if k % 16 == 0 else None
+    if k % 16 == 0:
+        assert torch.max((c - c64).abs() / (at.abs().amax(1)[:, None] * bt.abs().amax(1)[None, :])).item() < 6 * np.sqrt(k) * 2.0 ** 14 * 256.0 ** -7 * 16
+
+
 def test_gemm_split_f16_agrees_with_f32_mfma_in_the_cholesky():
     """The look-ahead Cholesky with split-float16 trailing updates against the same factorisation on the float32 MFMA
     (debug key 2 = 2): both factor the same matrix to float32 accuracy."""
