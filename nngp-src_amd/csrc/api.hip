@@ -157,7 +157,7 @@ struct nngp_model {
         if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
-        dev_free(i8.kplanes); dev_free(i8.kscale); dev_free(i8.zplanes); dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
+        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes); dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
@@ -316,20 +316,22 @@ constexpr int64_t kI8RowBlock = 2048;  // right-hand-side rows per pass (bounds 
 // GEMM's 128 x 128 tiles fill the chip better).  Debug key 5 = 50: float64 matrix pipe instead.
 bool use_i8s(const nngp_model* m, int64_t mp) { return m->np >= 4096 && mp >= 256 && NNGP_KNOB(5) != 50; }
 
-int ensure_i8s(nngp_model* m, int64_t mp) {
+int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
     I8Work& w = m->i8;
     if (NNGP_KNOB(5) == 51) { w.ns_k = w.ns_z = 4; w.cut = 3; }
     else if (NNGP_KNOB(5) == 52) { w.ns_k = w.ns_z = 6; w.cut = 5; }
     else { w.ns_k = w.ns_z = 5; w.cut = 4; }
-    if (w.kplanes == nullptr) {
+    w.k_rows = round_up(m->np_cap, 256);
+    if (pk.planes == nullptr) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
-        w.k_rows = round_up(m->np_cap, 256);
-        NNGP_TRY(dev_alloc(&w.kplanes, 6 * w.k_rows * m->np_cap));
-        NNGP_TRY(dev_alloc(&w.kscale, m->np_cap));
+        NNGP_TRY(dev_alloc(&pk.planes, 6 * w.k_rows * m->np_cap));
+        NNGP_TRY(dev_alloc(&pk.scale, m->np_cap));
+        NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(6 * w.k_rows * m->np_cap)));
+        pk.ready = false;
+    }
+    if (w.counters == nullptr) {
         NNGP_TRY(dev_alloc(&w.counters, 16));
         NNGP_HIP_CHECK(hipMemset(w.counters, 0, 16 * sizeof(int)));
-        NNGP_HIP_CHECK(hipMemset(w.kplanes, 0, (size_t)(6 * w.k_rows * m->np_cap)));
-        w.k_ready = false;
     }
     const int64_t rows = mp < kI8RowBlock ? mp : kI8RowBlock;
     if (rows > w.z_rows) {
@@ -344,32 +346,25 @@ int ensure_i8s(nngp_model* m, int64_t mp) {
     return 0;
 }
 
-// the digit planes of the float64 kernel (whole matrix, rows scaled by their maxima)
-int slice_k_planes(nngp_model* m, hipStream_t s) {
-    I8Work& w = m->i8;
-    // K is a kernel matrix (positive semi-definite): row i is bounded by sqrt(K_ii max_j K_jj) -- no pass over the matrix for the scales
-    NNGP_TRY(launch_i8s_diag_bound_scale(m->k64, m->ld, m->np, w.kscale, s));
-    NNGP_TRY(launch_i8s_slice_rows(m->k64, m->ld, m->np, m->np, w.ns_k, w.kscale, nullptr, w.kplanes, m->np_cap, w.k_rows * m->np_cap, s));
-    w.k_ns_done = w.ns_k;
-    w.k_ready = true;
-    return 0;
-}
-
-// out [mp, np] = rhs - z (K + reg I) for z = z64 (or another [mp, np] block), float64 grade
-int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s) {
+// out [mp, np] = beta cin + alpha z Kmat + gamma z on the int8 pipe, float64 grade; Kmat: a symmetric positive semi-definite
+// [np, np] kernel matrix (k64, or kaux64 beside an NTK fit) whose digit planes are kept in pk.
+// The planes are cut by the first product after the matrix changed, in stream order: 13 N^2 bytes of HBM traffic (2.7 ms at
+// N = 32768).  Measured and dropped (profiles/r3_i8s_slicing_placement.json): slicing beside the factorisation on a second stream
+// costs the Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768
+// small workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and
+// on a CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
+int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, double* out, const double* cin, double beta,
+                     double alpha, const double* z, double gamma, int64_t mp, hipStream_t s) {
     const int64_t np = m->np;
-    if (!use_i8s(m, mp)) {
-        NNGP_TRY(launch_gemm_nt_f64(out, np, rhs, np, z, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
-        return launch_axpby_mat(out, 1.0, z, -m->reg, np, mp, np, s);
-    }
-    NNGP_TRY(ensure_i8s(m, mp));
+    NNGP_TRY(ensure_i8s(m, mp, pk));
     I8Work& w = m->i8;
-    // The planes of K are cut by the first residual product after a fit, in stream order: 13 N^2 bytes of HBM traffic (2.7 ms at
-    // N = 32768).  Measured and dropped (scripts/i8s_ab.py, round 3): slicing beside the factorisation on a second stream costs the
-    // Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768 small
-    // workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on a
-    // CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
-    if (!w.k_ready || w.k_ns_done != w.ns_k) NNGP_TRY(slice_k_planes(m, s));
+    if (!pk.ready || pk.ns_done != w.ns_k) {
+        // a kernel matrix is positive semi-definite: row i is bounded by sqrt(K_ii max_j K_jj) -- no pass over the matrix for the scales
+        NNGP_TRY(launch_i8s_diag_bound_scale(kmat, kld, np, pk.scale, s));
+        NNGP_TRY(launch_i8s_slice_rows(kmat, kld, np, np, w.ns_k, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
+        pk.ns_done = w.ns_k;
+        pk.ready = true;
+    }
     I8Plan pl;
     NNGP_TRY(i8s_plan(w.ns_z, w.ns_k, w.cut, &pl));
     const int64_t nchunk = i8s_chunks(np);
@@ -377,12 +372,20 @@ int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z
         const int64_t mb = mp - r0 < kI8RowBlock ? mp - r0 : kI8RowBlock;
         const int64_t slab = mb * np;
         NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, w.ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
-        NNGP_TRY(launch_gemm_nt_i8s(w.partial, np, slab, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, w.kplanes, m->np_cap,
+        NNGP_TRY(launch_gemm_nt_i8s(w.partial, np, slab, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, pk.planes, m->np_cap,
                                     w.k_rows * m->np_cap, pl, mb, np, np, w.counters, 0, s));
-        NNGP_TRY(launch_i8s_combine(out + r0 * np, np, rhs + r0 * np, np, 1.0, -1.0, z + r0 * np, np, -m->reg, w.partial, np, slab,
-                                    (int)nchunk, pl.ndiag, w.zscale, w.kscale, mb, np, s));
+        NNGP_TRY(launch_i8s_combine(out + r0 * np, np, cin ? cin + r0 * np : nullptr, np, beta, alpha, z + r0 * np, np, gamma, w.partial, np,
+                                    slab, (int)nchunk, pl.ndiag, w.zscale, pk.scale, mb, np, s));
     }
     return 0;
+}
+
+// out [mp, np] = rhs - z (K + reg I) for z = z64 (or another [mp, np] block), float64 grade
+int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s) {
+    const int64_t np = m->np;
+    if (use_i8s(m, mp)) return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+    NNGP_TRY(launch_gemm_nt_f64(out, np, rhs, np, z, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
+    return launch_axpby_mat(out, 1.0, z, -m->reg, np, mp, np, s);
 }
 
 // the factor has float16-split copies (look-ahead factorisation) and the caller did not ask for the float32 path
@@ -700,7 +703,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     a.ld64 = a.ld32 = m->ld;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
     m->a32_built = false;
-    m->i8.k_ready = false;
+    m->i8.k.ready = false;
     if (a.sym) {  // whole matrix in one build: the float32 factorisation input falls out of the same epilogue
         if (m->get == NNGP_GET_NNGP) { a.nngp32 = m->a32; a.diag_add_nngp32 = m->reg; }
         else { a.ntk32 = m->a32; a.diag_add_ntk32 = m->reg; }
@@ -849,7 +852,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     m->solved = false;
     m->solve_pending = false;
     m->serving_ready = false;
-    m->i8.k_ready = false;
+    m->i8.k.ready = false;
     // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
@@ -1167,7 +1170,10 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     const bool full = (cov_mode == NNGP_COV_FULL);
     const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
     auto ntk_finish = [&]() -> int {    // from z64 = Theta_td (Theta_dd + reg I)^-1; K_tt already in ktt64 (full)
-        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd
+        if (use_i8s(m, mp))  // W = Z K_dd
+            NNGP_TRY(i8s_product_rows(m, m->i8.aux, m->kaux64, np, m->r64, nullptr, 0.0, 1.0, m->z64, 0.0, mp, s));
+        else
+            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));
         if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
             return launch_rowdot_f64(m->z64, ntk_cross, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);
         NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ntk_cross, -1.0, np, mp, np, s));  // G = W - K_td
@@ -1317,6 +1323,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(launch_kernel_build(a, m->arch, s));
         NNGP_TRY(launch_zero_pad_f64(m->kaux64, np, n, np, s));
         m->aux_ready = true;
+        m->i8.aux.ready = false;
     }
     const double* ktd_n = m->kaux64;  // NNGP cross kernel; x_test=None: K_dd itself
     if (!on_train) {

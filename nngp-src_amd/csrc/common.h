@@ -198,12 +198,15 @@ struct I8Plan {       // which digit-plane pairs are multiplied, grouped by diag
     int dstart[9];    // first pair of diagonal dd; dstart[ndiag] = npairs
     int pa[32], pb[32];
 };
-struct I8Work {       // one per model: digit planes of K and of a block of right-hand-side rows (api.hip)
-    int8_t* kplanes = nullptr;   // [6][k_rows][np_cap]: planes of the float64 kernel, row stride np_cap bytes
-    double* kscale = nullptr;    // [np_cap] row scales
-    int64_t k_rows = 0;
-    bool k_ready = false;        // the planes belong to the current kernel matrix
-    int k_ns_done = 5;           // planes per row they were cut into
+struct I8Planes {     // digit planes of one float64 kernel matrix: [6][rows][np_cap] int8, row stride np_cap bytes
+    int8_t* planes = nullptr;
+    double* scale = nullptr;     // [np_cap] row scales
+    bool ready = false;          // the planes belong to the current matrix
+    int ns_done = 0;             // planes per row they were cut into
+};
+struct I8Work {       // one per model (api.hip): planes of K (and of the NNGP kernel beside an NTK fit), of a block of right-hand-side rows
+    I8Planes k, aux;
+    int64_t k_rows = 0;          // rows per plane (np_cap up to the next multiple of 256)
     int8_t* zplanes = nullptr;   // [6][z_rows + 256][np_cap]
     double* zscale = nullptr;    // [z_rows]
     int64_t z_rows = 0;
