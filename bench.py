@@ -38,6 +38,7 @@ CONFIGS = {
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak (the roofline BASELINE.json's north star names)
 PEAK_F16_MFMA_TFLOPS = 2516.6  # dense f16/bf16 MFMA peak = 16 x the f32 one; the split-float16 GEMM spends 3 products per term
+PEAK_I8_MFMA_TOPS = 5033.2     # dense int8 MFMA peak = 2 x the f16 one (MI355X_MICROARCH.md, matrix-core table)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -336,6 +337,9 @@ def main():
             if ktimer["on"]:  # HIP events the library put around every trailing-update launch of this step's factorisation
                 nl, tms, tfl = model.update_timer_read()
                 ktimer["launches"] += nl; ktimer["ms"] += tms; ktimer["flops"] += tfl; ktimer["bytes"] += model.update_timer_bytes()
+            if rtimer["on"]:  # ... and around every int8 plane-product launch of this step's predict
+                nl, tms, tfl, tops = model.residual_timer_read()
+                rtimer["launches"] += nl; rtimer["ms"] += tms; rtimer["flops"] += tfl; rtimer["ops"] += tops
             for k, (a, b) in {"set_train": (e0, e1), "kernel_build": (e1, e2), "allgather": (e2, e3),
                               "cholesky": (e3, e4), "alpha_solve": (e4, e5), "posterior": (e5, e6)}.items():
                 stages.setdefault(k, []).append(a.elapsed_time(b))
@@ -361,9 +365,18 @@ def main():
             ktimer["on"] = True
         except _lib.NngpError:
             pass
+    # ... and of the posterior's residual products on the int8 pipe (k_gemm_nt_i8s) for `roofline_residual`
+    rtimer = {"on": False, "launches": 0, "ms": 0.0, "flops": 0.0, "ops": 0.0}
+    try:
+        model.residual_timer(True)
+        rtimer["on"] = True
+    except _lib.NngpError:
+        pass
     for _ in range(args.warmup):
         step()
     barrier()
+    if rtimer["on"]:
+        model.residual_timer_read()  # drop the warm-up launches
     stages = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -438,7 +451,8 @@ def main():
                                        "fit replicated on %d GPUs (no data-path collective), test rows sharded" % world),
                        "precision": "float64 kernel build + CG residual; float32 Cholesky (preconditioner) whose trailing updates run "
                                     "as split-float16 MFMA products (hi+lo, 3 per term, float32 accumulate); float64 means; variances: "
-                                    "float32 solves + one float64 residual product (level 1)"},
+                                    "float32-grade solves on the float16 pipe + one float64-GRADE residual product on the int8 pipe "
+                                    "(operands cut into exact 8-bit digit planes, 15 exact plane products, float64 combination; level 1)"},
             "roofline": None,  # filled in below: the dominant kernel when the library timed it, else the stage
             # Cholesky stage = the dominant cost.  `achieved` = algorithmic F_C / stage time.  Its matrix work runs on the
             # float16 pipe at 3 products per float32-grade term, so the hardware peak for it is PEAK_F16 / 3; the
@@ -459,8 +473,10 @@ def main():
                                    "frac": round(post_tflops / PEAK_F32_MFMA_TFLOPS, 4), "stage_ms": round(post_ms, 3),
                                    "work": "2NMd + 4NM + N^2 M (cross kernel, mean, variances) for this rank's %d test rows x world" % (m1 - m0)
                                            if world > 1 else "2NMd + 4NM + N^2 M (cross kernel, mean, variances)",
-                                   "note": "algorithmic count; executed: one float64 MFMA product 2 N^2 M (78.6 TF/s pipe), three float32-grade "
-                                           "triangular solves N^2 M each on the float16 pipe, the alpha CG on HBM"},
+                                   "note": "algorithmic count; executed: one float64-grade residual product 2 N^2 M as 15 exact int8 plane "
+                                           "products (k_gemm_nt_i8s, see roofline_residual; until round 3 one float64 MFMA product on the "
+                                           "78.6 TF/s pipe), three float32-grade triangular solves N^2 M each on the float16 pipe, the "
+                                           "alpha CG on HBM"},
             "roofline_k1": {"bound": "hbm", "achieved": round(k_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                             "frac": round(k_gbps / PEAK_HBM_GBPS, 4), "stage_ms": round(st["kernel_build"], 3),
                             "bytes": "8 N^2 + 8 N d (float64 K written once, X read once)" + ("" if world == 1 or not shard else " / world")},
@@ -499,6 +515,22 @@ def main():
             }
         else:
             result["roofline"] = dict(result["roofline_cholesky_stage"])
+        if rtimer["on"] and rtimer["launches"] > 0 and rtimer["ms"] > 0.0:
+            # the second-largest kernel, measured live like the first: HIP events around every k_gemm_nt_i8s launch on the stream
+            # it is launched on.  achieved = int8 operations executed (2 m n k x plane pairs) / summed duration.
+            r_tops = rtimer["ops"] / (rtimer["ms"] * 1e-3) / 1e12
+            result["roofline_residual"] = {
+                "bound": "mfma", "achieved": round(r_tops, 1), "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s (int8)",
+                "frac": round(r_tops / PEAK_I8_MFMA_TOPS, 4),
+                "kernel": "k_gemm_nt_i8s (the posterior's float64-grade residual products as exact int8 digit-plane products)",
+                "launches_per_step": round(rtimer["launches"] / args.steps, 2), "ms_per_step_in_kernel": round(rtimer["ms"] / args.steps, 3),
+                "plane_pairs": round(rtimer["ops"] / rtimer["flops"], 2),
+                "float64_equivalent_tflops": round(rtimer["flops"] / (rtimer["ms"] * 1e-3) / 1e12, 1),
+                "float64_mfma_peak": 78.6,
+                "note": "the float64 matrix pipe peaks at 78.6 TF/s (the kernel this replaced ran the same product at 68); the chip holds "
+                        "~1.6 GHz under this load (profiles/r3_i8s_pmc_summary.txt: MFMA pipe 73 % busy)",
+                "timer": "HIP events on the caller's stream around each launch (library: nngp_model_residual_timer), timed steps only",
+            }
         if shard_report is not None:
             result["shard"] = shard_report
         elif world > 1:

@@ -159,6 +159,13 @@ int nngp_model_update_timer_read(nngp_model* m, int64_t* launches, double* ms_to
 /* ... and their algorithmic bytes: C read and written once per launch (8 B per updated float32 entry) plus the operands' split
  * rows once (4 B per row and k) -- what a launch must move at least, for the roofline's `traffic` comparison. */
 int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total);
+/* Live timing of the posterior's residual products on the int8 matrix pipe (k_gemm_nt_i8s, gemm_i8s.hip; reference op: the
+ * covariance of predict_fn(..., compute_cov=True), train.py:157-158): with the timer on, every plane-product launch of
+ * nngp_model_predict is bracketed by a pair of HIP events on the caller's stream.  _read waits for them and returns what ran since
+ * the last read: the launches, their summed duration, the float64 flops they stand for (2 m n k) and the int8 operations executed
+ * (x the number of plane pairs), then starts over.  Any out pointer may be NULL. */
+int nngp_model_residual_timer(nngp_model* m, int32_t enable);
+int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total, double* int8_ops_total);
 /* alpha = (K + reg I)^-1 Y, [n, ny] f64, copied to a device buffer. */
 int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
 

@@ -157,7 +157,8 @@ struct nngp_model {
         if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
-        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes); dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
+        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes);
+        for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
@@ -372,8 +373,21 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
         const int64_t mb = mp - r0 < kI8RowBlock ? mp - r0 : kI8RowBlock;
         const int64_t slab = mb * np;
         NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, w.ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
+        const bool timed = w.timed && w.t_count < I8Work::kMaxTimed;
+        if (timed) {
+            const int t = w.t_count;
+            if (w.t0[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&w.t0[t]));
+            if (w.t1[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&w.t1[t]));
+            NNGP_HIP_CHECK(hipEventRecord(w.t0[t], s));
+        }
         NNGP_TRY(launch_gemm_nt_i8s(w.partial, np, slab, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, pk.planes, m->np_cap,
                                     w.k_rows * m->np_cap, pl, mb, np, np, w.counters, 0, s));
+        if (timed) {
+            const int t = w.t_count++;
+            NNGP_HIP_CHECK(hipEventRecord(w.t1[t], s));
+            w.t_flops[t] = 2.0 * (double)mb * (double)np * (double)np;
+            w.t_ops[t] = w.t_flops[t] * pl.npairs;
+        }
         NNGP_TRY(launch_i8s_combine(out + r0 * np, np, cin ? cin + r0 * np : nullptr, np, beta, alpha, z + r0 * np, np, gamma, w.partial, np,
                                     slab, (int)nchunk, pl.ndiag, w.zscale, pk.scale, mb, np, s));
     }
@@ -1038,6 +1052,33 @@ int nngp_model_update_timer_read(nngp_model* m, int64_t* launches, double* ms_to
     if (launches) *launches = m->la->tu_count;
     if (ms_total) *ms_total = ms;
     if (flops_total) *flops_total = fl;
+    return 0;
+}
+
+int nngp_model_residual_timer(nngp_model* m, int32_t enable) {
+    NNGP_REQUIRE(m != nullptr, "residual_timer: NULL model");
+    m->i8.timed = enable != 0;
+    m->i8.t_count = 0;
+    return 0;
+}
+
+int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total, double* int8_ops_total) {
+    NNGP_REQUIRE(m != nullptr, "residual_timer_read: NULL model");
+    I8Work& w = m->i8;
+    double ms = 0.0, fl = 0.0, ops = 0.0;
+    for (int t = 0; t < w.t_count; ++t) {
+        NNGP_HIP_CHECK(hipEventSynchronize(w.t1[t]));
+        float e = 0.0f;
+        NNGP_HIP_CHECK(hipEventElapsedTime(&e, w.t0[t], w.t1[t]));
+        ms += e;
+        fl += w.t_flops[t];
+        ops += w.t_ops[t];
+    }
+    if (launches) *launches = w.t_count;
+    if (ms_total) *ms_total = ms;
+    if (flops_total) *flops_total = fl;
+    if (int8_ops_total) *int8_ops_total = ops;
+    w.t_count = 0;
     return 0;
 }
 

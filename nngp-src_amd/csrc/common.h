@@ -213,6 +213,13 @@ struct I8Work {       // one per model (api.hip): planes of K (and of the NNGP k
     int32_t* partial = nullptr;  // [chunks][diagonals][z_rows][np_cap] exact plane products
     int* counters = nullptr;     // work counters of the persistent grid
     int ns_k = 5, ns_z = 5, cut = 4;
+    // live timing of the plane-product launches since the timer was last read (nngp_model_residual_timer_read)
+    static constexpr int kMaxTimed = 64;
+    bool timed = false;
+    hipEvent_t t0[kMaxTimed] = {}, t1[kMaxTimed] = {};
+    int t_count = 0;
+    double t_ops[kMaxTimed] = {};   // executed int8 multiply-adds x 2
+    double t_flops[kMaxTimed] = {}; // algorithmic: the float64 product they stand for, 2 m n k
 };
 int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl);
 int64_t i8s_chunks(int64_t k);  // K chunks (of <= 16384) a product over k columns is cut into

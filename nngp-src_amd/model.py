@@ -238,6 +238,17 @@ class GPModel:
         self._check(self.lib.nngp_model_update_timer_bytes(self.handle, ctypes.byref(b)))
         return float(b.value)
 
+    def residual_timer(self, enable=True):
+        """Live HIP-event timing of the posterior's int8 plane products (k_gemm_nt_i8s); see residual_timer_read."""
+        self._check(self.lib.nngp_model_residual_timer(self.handle, 1 if enable else 0))
+
+    def residual_timer_read(self):
+        """(launches, total ms, float64 flops stood for, int8 operations executed) since the last read (waits for them)."""
+        n = ctypes.c_int64(0)
+        ms, fl, ops = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self.lib.nngp_model_residual_timer_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ops)))
+        return int(n.value), float(ms.value), float(fl.value), float(ops.value)
+
     def alpha(self):
         import torch
         out = torch.empty((self.n, self.ny), dtype=torch.float64, device=self.device)
