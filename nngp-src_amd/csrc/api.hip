@@ -118,6 +118,7 @@ struct nngp_model {
     // Sliced int8 copies of K for the residual products of the covariance (gemm_i8s.hip): allocated and cut by the first predict
     // that takes that path, cut again after every change of K.
     I8Work i8{};
+    bool i8_suspended = false;  // prepare_serving: the explicit inverse is refined against float64 residuals proper
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
     // Diagonal shift of the float32 factor's input.  = reg, unless the float32 factorisation of K + reg I broke down
@@ -157,7 +158,7 @@ struct nngp_model {
         if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
-        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes);
+        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.zplanes);
         for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
@@ -313,9 +314,15 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
 // ---- float64-grade residual products on the int8 matrix pipe (gemm_i8s.hip) ----
 constexpr int64_t kI8RowBlock = 2048;  // right-hand-side rows per pass (bounds the int32 partial buffer)
 
-// Worth it from a few thousand training rows and two 128-row tiles of right-hand sides on (256 x 256 tiles; below that the float64
-// GEMM's 128 x 128 tiles fill the chip better).  Debug key 5 = 50: float64 matrix pipe instead.
-bool use_i8s(const nngp_model* m, int64_t mp) { return m->np >= 4096 && mp >= 256 && NNGP_KNOB(5) != 50; }
+// Where it pays (profiles/r3_i8s_crossover.jsonl, predict with the diagonal variance, float64 / int8 residual, ms): a predict that also
+// has to cut the planes of K (the first after a fit) wins from two 128-row tiles of right-hand sides on -- N = 2048, M = 256: 0.57 /
+// 0.50; N = 8192: M = 128 2.04 / 2.39, M = 256 2.45 / 2.56, M = 512 3.63 / 3.06, M = 1024 5.02 / 3.99; N = 16384, M = 1024: 15.5 / 11.4
+// -- later predicts on the same fit from any size on (N = 16384, M = 128: 4.51 / 4.42).  Debug key 5 = 50: float64 matrix pipe instead.
+bool use_i8s(const nngp_model* m, int64_t mp) {
+    if (m->i8_suspended) return false;
+    if (NNGP_KNOB(5) == 54) return true;  // timing experiment: at any size (scripts/i8s_crossover.py)
+    return m->np >= 2048 && mp >= 256 && NNGP_KNOB(5) != 50;
+}
 
 int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
     I8Work& w = m->i8;
@@ -394,10 +401,16 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
     return 0;
 }
 
-// out [mp, np] = rhs - z (K + reg I) for z = z64 (or another [mp, np] block), float64 grade
-int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s) {
+// out [mp, np] = rhs - z (K + reg I) for z = z64 (or another [mp, np] block).
+// first_residual: z comes straight from the float32 solves, so the residual is ~1e-4 of rhs and the int8 product's error floor
+// (2^-32 sqrt(N) of the row maxima with 5 x 5 planes, ~1e-3 of such a residual) is harmless: the NNGP level-1 variance moves by
+// 2e-7 (N = 32768) .. 7e-7 (ill-conditioned sweep case), a first correction sweep loses nothing.  Every LATER residual is ~1e-8 of
+// rhs and needs the float64 pipe proper -- measured with the int8 product there (scripts/i8s_hard_case.py): NTK variances off by
+// 3e-5 .. 2e-4 (first order in the rows' error) against 1e-8, NNGP level 2 at 1e-7 instead of 1e-8, the explicit inverse of the
+// serving mode stuck four digits short of float64 (serving variances 4e-3 off).
+int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s, bool first_residual) {
     const int64_t np = m->np;
-    if (use_i8s(m, mp)) return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+    if (first_residual && use_i8s(m, mp)) return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
     NNGP_TRY(launch_gemm_nt_f64(out, np, rhs, np, z, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
     return launch_axpby_mat(out, 1.0, z, -m->reg, np, mp, np, s);
 }
@@ -461,7 +474,7 @@ int refined_solve_rows(nngp_model* m, const double* rhs, int64_t mp, int sweeps,
     NNGP_TRY(apply_inverse_f32(m, mp, s));
     NNGP_TRY(launch_f32_to_f64_mat(m->b32, np, m->z64, np, mp, np, false, s));
     for (int it = 0; it < sweeps + (final_residual ? 1 : 0); ++it) {
-        NNGP_TRY(residual_rows(m, m->r64, rhs, m->z64, mp, s));
+        NNGP_TRY(residual_rows(m, m->r64, rhs, m->z64, mp, s, it == 0));
         if (it == sweeps) break;
         NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
         NNGP_TRY(apply_inverse_f32(m, mp, s));
@@ -1152,6 +1165,10 @@ int nngp_model_prepare_serving(nngp_model* m, void* stream) {
     }
     const bool weak = m->iters >= 8 || m->reg_fac > m->reg;
     const double shift = (m->reg > 0.0 && m->reg_fac > m->reg) ? sqrt(m->reg_fac / m->reg) : 1.0;
+    // The serving predictions SQUARE the inverse's error (second-order formula) on top of a cancellation of 1e3 .. 1e6: the
+    // inverse has to converge to float64 accuracy proper, and the int8 residual's floor (2^-32 of the row maxima) stops the sweeps
+    // four digits short of it -- measured: 4e-3 in the serving variances at N = 2500 against 1e-7 (scripts/i8s_hard_case.py).
+    struct Suspend { bool& f; explicit Suspend(bool& b) : f(b) { f = true; } ~Suspend() { f = false; } } suspend(m->i8_suspended);
     for (int64_t r0 = 0; r0 < n; r0 += blk) {
         const int64_t rows = (n - r0 < blk) ? n - r0 : blk, rp = round_up(rows, TB);
         NNGP_TRY(launch_identity_rows(m->ktd64, np, np, r0, rows, rp, s));
@@ -1211,10 +1228,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     const bool full = (cov_mode == NNGP_COV_FULL);
     const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
     auto ntk_finish = [&]() -> int {    // from z64 = Theta_td (Theta_dd + reg I)^-1; K_tt already in ktt64 (full)
-        if (use_i8s(m, mp))  // W = Z K_dd
-            NNGP_TRY(i8s_product_rows(m, m->i8.aux, m->kaux64, np, m->r64, nullptr, 0.0, 1.0, m->z64, 0.0, mp, s));
-        else
-            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));
+        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd (float64 proper: its error is the variance's)
         if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
             return launch_rowdot_f64(m->z64, ntk_cross, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);
         NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ntk_cross, -1.0, np, mp, np, s));  // G = W - K_td
@@ -1265,11 +1279,11 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         if (!serving) return refined_solve_rows(m, ktd, mp, sweeps, final_residual, s);
         NNGP_TRY(launch_gemm_nt_f64(m->z64, np, nullptr, 0, ktd, np, m->ainv64, np, mp, np, np, 1.0, 0.0, s));
         if (m->serving_weak) {  // ill-conditioned fit: X is less accurate; one correction step with X as the solver
-            NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s));
+            NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s, false));
             NNGP_TRY(launch_gemm_nt_f64(m->z64, np, m->z64, np, m->r64, np, m->ainv64, np, mp, np, np, 1.0, 1.0, s));
         }
         if (final_residual) {
-            NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s));
+            NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s, false));
         }
         return 0;
     };
@@ -1364,7 +1378,6 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(launch_kernel_build(a, m->arch, s));
         NNGP_TRY(launch_zero_pad_f64(m->kaux64, np, n, np, s));
         m->aux_ready = true;
-        m->i8.aux.ready = false;
     }
     const double* ktd_n = m->kaux64;  // NNGP cross kernel; x_test=None: K_dd itself
     if (!on_train) {
@@ -1431,7 +1444,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             } else if (check_kind == 4) {
                 // level 1: r64 is the residual of z64 already
             } else {
-                NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s));
+                NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s, false));
             }
             if (check_kind == 3)  // tolerance from what the second sweep did to the variance (rows.tol holds z . k)
                 NNGP_TRY(launch_rows_prepare_ntk(m->rows.delta, m->rows.coef, m->rows.tol, var_or_cov, full ? mt + 1 : 1, mt,

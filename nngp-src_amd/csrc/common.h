@@ -204,8 +204,8 @@ struct I8Planes {     // digit planes of one float64 kernel matrix: [6][rows][np
     bool ready = false;          // the planes belong to the current matrix
     int ns_done = 0;             // planes per row they were cut into
 };
-struct I8Work {       // one per model (api.hip): planes of K (and of the NNGP kernel beside an NTK fit), of a block of right-hand-side rows
-    I8Planes k, aux;
+struct I8Work {       // one per model (api.hip): planes of K and of a block of right-hand-side rows
+    I8Planes k;
     int64_t k_rows = 0;          // rows per plane (np_cap up to the next multiple of 256)
     int8_t* zplanes = nullptr;   // [6][z_rows + 256][np_cap]
     double* zscale = nullptr;    // [z_rows]
