@@ -1442,7 +1442,10 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             if (check_kind == 2) {
                 NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ktd, -1.0, np, mp, np, s));  // back from G = K_td + R to R
             } else if (check_kind == 4) {
-                // level 1: r64 is the residual of z64 already
+                // level 1: r64 is the residual of z64 already -- but if it came from the int8 product, its error floor (~1e-3 of it)
+                // would stay in the recursively updated residual and in the rows the CG converges to (seen in the parity sweep:
+                // continued rows at 1e-6 .. 9e-6 instead of 1e-9): the continuation starts from the float64 residual proper
+                if (use_i8s(m, mp)) NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s, false));
             } else {
                 NNGP_TRY(residual_rows(m, m->r64, ktd, m->z64, mp, s, false));
             }
