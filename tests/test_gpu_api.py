@@ -465,3 +465,41 @@ def test_pool_select_on_the_device_matches_the_host_build(golden_dir):
                                             _lib_mod.stream_ptr()))
         np.testing.assert_array_equal(idx.cpu().numpy(), c_abi.pool_select(m_ref, v_ref, 150, biased=bool(biased), seed=10))
     model.close()
+
+
+def test_int8_residual_path_against_the_float64_residual():
+    """The level-1 variance with its residual product on the int8 pipe (exact digit planes, gemm_i8s.hip; reference op: the
+    covariance of predict_fn(..., compute_cov=True), train.py:157-158) against the same predict with the float64 product
+    (timing-knob key 5 = 50) and against the oracle; the live timer says which path ran: M > 128 rows on a fit of N >= 2048 take
+    it, a small block of rows and the NTK's later residuals do not."""
+    x, y = synth.synthetic_queries(2600, 24, seed=41)
+    xt, _ = synth.synthetic_queries(300, 24, seed=42)
+    model = GPModel(2600, 24, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+    model.residual_timer(True)
+    mean_i8, var_i8 = model.predict(xt, cov="diag")
+    launches, ms, flops, ops = model.residual_timer_read()
+    assert launches == 1 and ops == 15 * flops and flops == 2.0 * 384 * 2688 * 2688 and ms > 0.0
+    model.predict(xt[:100], cov="diag")
+    assert model.residual_timer_read()[0] == 0   # 128 padded rows: float64 pipe
+    model.debug_set(5, 50)
+    mean_64, var_64 = model.predict(xt, cov="diag")
+    assert model.residual_timer_read()[0] == 0
+    model.debug_set(5, 0)
+    np.testing.assert_array_equal(mean_i8, mean_64)  # the mean does not pass through the residual
+    assert np.max(np.abs(var_i8 - var_64) / np.abs(var_64)) < 1e-6
+    import c_oracle
+    post = c_oracle.fit(x, y, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3)
+    mean_ref, var_ref = c_oracle.predict_nngp(post, xt, 1)
+    assert np.max(np.abs(var_i8 - var_ref[:300]) / np.abs(var_ref[:300])) < 1e-5
+    assert np.max(np.abs(mean_i8 - mean_ref) / np.maximum(1.0, np.abs(mean_ref))) < 1e-6
+    model.close()
+    # NTK: the first correction sweep's residual only (one launch per predict), the later residual and W = Z K_dd on the float64 pipe
+    ntk = GPModel(2600, 24, [1.0, 1.0], [0.0, 0.0], get="ntk", diag_reg=1e-3, knobs=True).fit(x, y)
+    ntk.residual_timer(True)
+    _, v_i8 = ntk.predict(xt, cov="diag")
+    assert ntk.residual_timer_read()[0] == 1
+    ntk.debug_set(5, 50)
+    _, v_64 = ntk.predict(xt, cov="diag")
+    ntk.debug_set(5, 0)
+    assert np.max(np.abs(v_i8 - v_64) / np.abs(v_64)) < 1e-7
+    ntk.close()
