@@ -118,6 +118,9 @@ struct nngp_model {
     // Sliced int8 copies of K for the residual products of the covariance (gemm_i8s.hip): allocated and cut by the first predict
     // that takes that path, cut again after every change of K.
     I8Work i8{};
+    hipEvent_t ev_i8 = nullptr;  // the planes of K were cut on the solve stream (beside the first blocked solves of a predict)
+    bool i8_k_pending = false;   // ... and the consumer has not waited for that yet
+    bool i8_unavailable = false; // no room for its workspace on this device: float64 pipe from then on
     bool i8_suspended = false;  // prepare_serving: the explicit inverse is refined against float64 residuals proper
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
@@ -158,6 +161,7 @@ struct nngp_model {
         if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
+        if (ev_i8) (void)hipEventDestroy(ev_i8);
         dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.zplanes);
         for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
@@ -319,22 +323,47 @@ constexpr int64_t kI8RowBlock = 2048;  // right-hand-side rows per pass (bounds 
 // 0.50; N = 8192: M = 128 2.04 / 2.39, M = 256 2.45 / 2.56, M = 512 3.63 / 3.06, M = 1024 5.02 / 3.99; N = 16384, M = 1024: 15.5 / 11.4
 // -- later predicts on the same fit from any size on (N = 16384, M = 128: 4.51 / 4.42).  Debug key 5 = 50: float64 matrix pipe instead.
 bool use_i8s(const nngp_model* m, int64_t mp) {
-    if (m->i8_suspended) return false;
+    if (m->i8_suspended || m->i8_unavailable) return false;
     if (NNGP_KNOB(5) == 54) return true;  // timing experiment: at any size (scripts/i8s_crossover.py)
     return m->np >= 2048 && mp >= 256 && NNGP_KNOB(5) != 50;
 }
 
+#ifdef NNGP_TIMING_KNOBS
+constexpr int kI8MaxPlanes = 6;  // the knobs build can try 6 x 6 planes (key 5 = 52)
+#else
+constexpr int kI8MaxPlanes = 5;
+#endif
+
+template <typename T>
+static bool soft_alloc(T** p, int64_t count) {  // false (and no sticky error) when the device has no room
+    *p = nullptr;
+    if (NNGP_KNOB(5) == 55) return false;  // test: as if the device were full
+    if (hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)count) == hipSuccess) return true;
+    (void)hipGetLastError();
+    *p = nullptr;
+    return false;
+}
+
+// Workspace of the int8 residual path: 5 N^2 bytes of digit planes + the planes and exact plane products of one block of rows.
+// Returns 1 -- and the model stays on the float64 pipe from then on -- when the device has no room for them (a kernel matrix that
+// fills most of the 288 GB leaves none): the int8 path is an accelerator, not a requirement.
 int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
     I8Work& w = m->i8;
     if (NNGP_KNOB(5) == 51) { w.ns_k = w.ns_z = 4; w.cut = 3; }
     else if (NNGP_KNOB(5) == 52) { w.ns_k = w.ns_z = 6; w.cut = 5; }
     else { w.ns_k = w.ns_z = 5; w.cut = 4; }
     w.k_rows = round_up(m->np_cap, 256);
+    auto give_up = [&]() -> int {
+        dev_free(pk.planes); dev_free(pk.scale); dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
+        pk.ready = false;
+        w.z_rows = 0;
+        m->i8_unavailable = true;
+        return 1;
+    };
     if (pk.planes == nullptr) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
-        NNGP_TRY(dev_alloc(&pk.planes, 6 * w.k_rows * m->np_cap));
-        NNGP_TRY(dev_alloc(&pk.scale, m->np_cap));
-        NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(6 * w.k_rows * m->np_cap)));
+        if (!soft_alloc(&pk.planes, kI8MaxPlanes * w.k_rows * m->np_cap) || !soft_alloc(&pk.scale, m->np_cap)) return give_up();
+        NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(kI8MaxPlanes * w.k_rows * m->np_cap)));
         pk.ready = false;
     }
     if (w.counters == nullptr) {
@@ -345,34 +374,45 @@ int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
     if (rows > w.z_rows) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
-        NNGP_TRY(dev_alloc(&w.zplanes, 6 * (rows + 256) * m->np_cap));
-        NNGP_TRY(dev_alloc(&w.zscale, rows));
-        NNGP_TRY(dev_alloc(&w.partial, i8s_chunks(m->np_cap) * 8 * rows * m->np_cap));
-        NNGP_HIP_CHECK(hipMemset(w.zplanes, 0, (size_t)(6 * (rows + 256) * m->np_cap)));
+        w.z_rows = 0;
+        if (!soft_alloc(&w.zplanes, kI8MaxPlanes * (rows + 256) * m->np_cap) || !soft_alloc(&w.zscale, rows) ||
+            !soft_alloc(&w.partial, i8s_chunks(m->np_cap) * kI8MaxPlanes * rows * m->np_cap))  // diagonals = cut + 1 <= planes
+            return give_up();
+        NNGP_HIP_CHECK(hipMemset(w.zplanes, 0, (size_t)(kI8MaxPlanes * (rows + 256) * m->np_cap)));
         w.z_rows = rows;
     }
     return 0;
 }
 
+// the digit planes of a kernel matrix.  It is positive semi-definite: row i is bounded by sqrt(K_ii max_j K_jj) -- no pass over the
+// matrix for the scales
+int i8s_cut_planes(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, hipStream_t s) {
+    I8Work& w = m->i8;
+    NNGP_TRY(launch_i8s_diag_bound_scale(kmat, kld, m->np, pk.scale, s));
+    NNGP_TRY(launch_i8s_slice_rows(kmat, kld, m->np, m->np, w.ns_k, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
+    pk.ns_done = w.ns_k;
+    pk.ready = true;
+    return 0;
+}
+
 // out [mp, np] = beta cin + alpha z Kmat + gamma z on the int8 pipe, float64 grade; Kmat: a symmetric positive semi-definite
 // [np, np] kernel matrix (k64, or kaux64 beside an NTK fit) whose digit planes are kept in pk.
-// The planes are cut by the first product after the matrix changed, in stream order: 13 N^2 bytes of HBM traffic (2.7 ms at
-// N = 32768).  Measured and dropped (profiles/r3_i8s_slicing_placement.json): slicing beside the factorisation on a second stream
-// costs the Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768
-// small workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and
-// on a CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
+// The planes (13 N^2 bytes of HBM traffic to cut: 2.7 ms at N = 32768) are cut once per change of the matrix: by nngp_model_predict
+// on the solve stream beside its first blocked solves (-0.8 ms against stream order at N = 32768), else here in stream order.
+// Measured and dropped (profiles/r3_i8s_slicing_placement.json): slicing beside the FACTORISATION on a second stream costs the
+// Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768 small
+// workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on a
+// CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
 int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, double* out, const double* cin, double beta,
                      double alpha, const double* z, double gamma, int64_t mp, hipStream_t s) {
     const int64_t np = m->np;
-    NNGP_TRY(ensure_i8s(m, mp, pk));
-    I8Work& w = m->i8;
+    I8Work& w = m->i8;  // workspace: ensure_i8s, by the caller
     if (!pk.ready || pk.ns_done != w.ns_k) {
-        // a kernel matrix is positive semi-definite: row i is bounded by sqrt(K_ii max_j K_jj) -- no pass over the matrix for the scales
-        NNGP_TRY(launch_i8s_diag_bound_scale(kmat, kld, np, pk.scale, s));
-        NNGP_TRY(launch_i8s_slice_rows(kmat, kld, np, np, w.ns_k, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
-        pk.ns_done = w.ns_k;
-        pk.ready = true;
+        NNGP_TRY(i8s_cut_planes(m, pk, kmat, kld, s));
+    } else if (m->i8_k_pending) {  // cut on the solve stream at the start of this predict
+        NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_i8, 0));
     }
+    m->i8_k_pending = false;
     I8Plan pl;
     NNGP_TRY(i8s_plan(w.ns_z, w.ns_k, w.cut, &pl));
     const int64_t nchunk = i8s_chunks(np);
@@ -410,7 +450,11 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
 // serving mode stuck four digits short of float64 (serving variances 4e-3 off).
 int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s, bool first_residual) {
     const int64_t np = m->np;
-    if (first_residual && use_i8s(m, mp)) return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+    if (first_residual && use_i8s(m, mp)) {
+        const int rc = ensure_i8s(m, mp, m->i8.k);
+        if (rc == 0) return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+        if (rc != 1) return rc;  // 1: no room for the planes -- the float64 pipe below
+    }
     NNGP_TRY(launch_gemm_nt_f64(out, np, rhs, np, z, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
     return launch_axpby_mat(out, 1.0, z, -m->reg, np, mp, np, s);
 }
@@ -1223,6 +1267,21 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // (overlapping it), and the mean follows once alpha is there.
     // Levels >= 2 check afterwards whether the fixed number of correction sweeps was enough (cov_adaptive below):
     // 0 nothing to check, 1 NNGP diag, 2 NNGP full, 3 NTK, 4 NNGP diag at level 1.
+    // A predict whose covariance will take the int8 residual product right after a fit: the digit planes of K (13 N^2 bytes of HBM
+    // traffic) are cut on the solve stream while this stream runs the first two blocked solves, whose launches leave most of the
+    // chip's bandwidth and, between them, its compute units idle.  (debug key 5 = 53: in stream order where they are first needed)
+    if (cov_mode != NNGP_COV_NONE && m->var_refine >= 1 && use_i8s(m, mp) && !(m->serving_ready && !is_ntk) && NNGP_KNOB(5) != 53) {
+        const int rc_i8 = ensure_i8s(m, mp, m->i8.k);
+        if (rc_i8 != 0 && rc_i8 != 1) return rc_i8;
+        if (rc_i8 == 0 && (!m->i8.k.ready || m->i8.k.ns_done != m->i8.ns_k)) {
+            if (m->ev_i8 == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_i8, hipEventDisableTiming));
+            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, s));  // K is complete; earlier readers of the planes are behind us
+            NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_i8, 0));
+            NNGP_TRY(i8s_cut_planes(m, m->i8.k, m->k64, m->ld, m->solve_stream));
+            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, m->solve_stream));
+            m->i8_k_pending = true;
+        }
+    }
     int check_kind = 0;
     bool z_valid = false;  // z64 ends up holding the rows K_td (K + reg I)^-1 (to first order): the mean can be corrected through them
     const bool full = (cov_mode == NNGP_COV_FULL);

@@ -23,7 +23,7 @@ def step():
     return (t1 - t0) * 1e3, (t2 - t1) * 1e3, mean, var
 out = {"config": cfg}
 ref = None
-for name, key in (("f64", 50), ("i8s_5x5_cut4", 0), ("i8s_4x4_cut3", 51), ("i8s_6x6_cut5", 52)):
+for name, key in (("f64", 50), ("i8s_planes_beside_the_solves", 0), ("i8s_planes_in_stream_order", 53), ("i8s_planes_beside_the_solves_again", 0)):
     lib.nngp_debug_set(5, key)
     for _ in range(2): step()
     ts = [step() for _ in range(4)]

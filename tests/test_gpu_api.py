@@ -493,6 +493,19 @@ def test_int8_residual_path_against_the_float64_residual():
     assert np.max(np.abs(var_i8 - var_ref[:300]) / np.abs(var_ref[:300])) < 1e-5
     assert np.max(np.abs(mean_i8 - mean_ref) / np.maximum(1.0, np.abs(mean_ref))) < 1e-6
     model.close()
+    # no room for the digit planes (timing-knob key 5 = 55: every workspace allocation of the int8 path fails): the model stays on
+    # the float64 pipe, with the float64 path's results
+    full = GPModel(2600, 24, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+    full.debug_set(5, 55)
+    full.residual_timer(True)
+    mean_f, var_f = full.predict(xt, cov="diag")
+    full.debug_set(5, 0)
+    assert full.residual_timer_read()[0] == 0
+    np.testing.assert_array_equal(var_f, var_64)
+    _, var_f2 = full.predict(xt, cov="diag")   # ... and does not try again
+    assert full.residual_timer_read()[0] == 0
+    np.testing.assert_array_equal(var_f2, var_64)
+    full.close()
     # NTK: the first correction sweep's residual only (one launch per predict), the later residual and W = Z K_dd on the float64 pipe
     ntk = GPModel(2600, 24, [1.0, 1.0], [0.0, 0.0], get="ntk", diag_reg=1e-3, knobs=True).fit(x, y)
     ntk.residual_timer(True)
