@@ -421,7 +421,7 @@ def main():
             (rep,) = max_over_ranks([(time.perf_counter() - tr) / 2 * 1e3])
             shard_report["replicate_layout_ms_per_step"] = round(rep, 3)
 
-    traffic, traffic_src, k_traffic = None, None, None
+    traffic, traffic_src, k_traffic, r_traffic = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg_name)
     if os.path.exists(tpath):  # HBM bytes of the Cholesky kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
         _pm = json.load(open(tpath))
@@ -430,6 +430,8 @@ def main():
         if _k and _k.get("calls"):
             k_traffic = (_k["fetch_bytes"] + _k["write_bytes"]) / _k["calls"]
         traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
+        _r = _pm.get("kernels", {}).get("k_gemm_nt_i8s")
+        r_traffic = (_r["fetch_bytes"] + _r["write_bytes"]) / _r["calls"] if _r and _r.get("calls") else None
     if rank == 0:
         fl = flop_model(n, d, m, n_relu)
         ms = elapsed / args.steps * 1e3
@@ -519,12 +521,17 @@ def main():
             # the second-largest kernel, measured live like the first: HIP events around every k_gemm_nt_i8s launch on the stream
             # it is launched on.  achieved = int8 operations executed (2 m n k x plane pairs) / summed duration.
             r_tops = rtimer["ops"] / (rtimer["ms"] * 1e-3) / 1e12
+            n_pad, m_pad = -(-n // 128) * 128, -(-(m1 - m0) // 128) * 128
             result["roofline_residual"] = {
                 "bound": "mfma", "achieved": round(r_tops, 1), "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s (int8)",
                 "frac": round(r_tops / PEAK_I8_MFMA_TOPS, 4),
                 "kernel": "k_gemm_nt_i8s (the posterior's float64-grade residual products as exact int8 digit-plane products)",
                 "launches_per_step": round(rtimer["launches"] / args.steps, 2), "ms_per_step_in_kernel": round(rtimer["ms"] / args.steps, 3),
                 "plane_pairs": round(rtimer["ops"] / rtimer["flops"], 2),
+                # algorithmic bytes per launch: the digit planes of both operands read once + the int32 plane products written once
+                "algorithmic_bytes_per_launch": round((5.0 * (n_pad + m_pad) * n_pad + 4.0 * 5 * m_pad * n_pad * max(1, -(-n_pad // 16384)))
+                                                      * (rtimer["flops"] / rtimer["launches"]) / (2.0 * m_pad * n_pad * n_pad), 1),
+                "traffic": r_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_i8s, per launch") if r_traffic else None,
                 "float64_equivalent_tflops": round(rtimer["flops"] / (rtimer["ms"] * 1e-3) / 1e12, 1),
                 "float64_mfma_peak": 78.6,
                 "note": "the float64 matrix pipe peaks at 78.6 TF/s (the kernel this replaced ran the same product at 68); the chip holds "
