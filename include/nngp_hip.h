@@ -166,6 +166,11 @@ int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total);
  * (x the number of plane pairs), then starts over.  Any out pointer may be NULL. */
 int nngp_model_residual_timer(nngp_model* m, int32_t enable);
 int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total, double* int8_ops_total);
+/* Guard of that path.  The first predict of a fit that forms a level-1 variance with the int8 residual also estimates what the
+ * digit pairs it dropped may have cost the variances (|z|_2 x the dropped pairs' random-sign sum, relative to each variance; maximum
+ * over the rows) and reads it back once; above 1e-5 the predict is redone with the float64 product and the fit stays on the float64
+ * pipe.  ratio: that estimate for the current fit (-1: not measured yet); distrusted: 1 if the fit was taken off the int8 path. */
+int nngp_model_residual_floor(nngp_model* m, double* ratio, int32_t* distrusted);
 /* alpha = (K + reg I)^-1 Y, [n, ny] f64, copied to a device buffer. */
 int nngp_model_alpha(nngp_model* m, double* alpha_out, void* stream);
 

@@ -121,6 +121,11 @@ struct nngp_model {
     hipEvent_t ev_i8 = nullptr;  // the planes of K were cut on the solve stream (beside the first blocked solves of a predict)
     bool i8_k_pending = false;   // ... and the consumer has not waited for that yet
     bool i8_unavailable = false; // no room for its workspace on this device: float64 pipe from then on
+    // Guard of the int8 residual (once per fit, on the first predict that used it for a level-1 variance): estimate of what the dropped
+    // digit pairs may have cost the variances, relative to them (k_i8s_floor_ratio); above kI8FloorThr the predict is redone on the
+    // float64 pipe and the fit stays there.
+    bool i8_checked = false, i8_distrusted = false, i8_used_now = false;
+    double i8_floor_ratio = -1.0;
     bool i8_suspended = false;  // prepare_serving: the explicit inverse is refined against float64 residuals proper
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
@@ -316,6 +321,9 @@ int ensure_lt_split(nngp_model* m, hipStream_t s) {
 
 
 // ---- float64-grade residual products on the int8 matrix pipe (gemm_i8s.hip) ----
+// Estimated |z . dr| / variance above which a fit is taken off the int8 residual: level 1 is itself 1e-6 .. 5e-6 from the converged
+// variance; the bench fits sit at ~1e-7 (nngp_model_residual_floor)
+constexpr double kI8FloorThr = 1e-5;
 constexpr int64_t kI8RowBlock = 2048;  // right-hand-side rows per pass (bounds the int32 partial buffer)
 
 // Where it pays (profiles/r3_i8s_crossover.jsonl, predict with the diagonal variance, float64 / int8 residual, ms): a predict that also
@@ -323,7 +331,7 @@ constexpr int64_t kI8RowBlock = 2048;  // right-hand-side rows per pass (bounds 
 // 0.50; N = 8192: M = 128 2.04 / 2.39, M = 256 2.45 / 2.56, M = 512 3.63 / 3.06, M = 1024 5.02 / 3.99; N = 16384, M = 1024: 15.5 / 11.4
 // -- later predicts on the same fit from any size on (N = 16384, M = 128: 4.51 / 4.42).  Debug key 5 = 50: float64 matrix pipe instead.
 bool use_i8s(const nngp_model* m, int64_t mp) {
-    if (m->i8_suspended || m->i8_unavailable) return false;
+    if (m->i8_suspended || m->i8_unavailable || m->i8_distrusted) return false;
     if (NNGP_KNOB(5) == 54) return true;  // timing experiment: at any size (scripts/i8s_crossover.py)
     return m->np >= 2048 && mp >= 256 && NNGP_KNOB(5) != 50;
 }
@@ -362,7 +370,7 @@ int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
     };
     if (pk.planes == nullptr) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
-        if (!soft_alloc(&pk.planes, kI8MaxPlanes * w.k_rows * m->np_cap) || !soft_alloc(&pk.scale, m->np_cap)) return give_up();
+        if (!soft_alloc(&pk.planes, kI8MaxPlanes * w.k_rows * m->np_cap) || !soft_alloc(&pk.scale, m->np_cap + 1)) return give_up();
         NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(kI8MaxPlanes * w.k_rows * m->np_cap)));
         pk.ready = false;
     }
@@ -390,6 +398,7 @@ int i8s_cut_planes(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld,
     I8Work& w = m->i8;
     NNGP_TRY(launch_i8s_diag_bound_scale(kmat, kld, m->np, pk.scale, s));
     NNGP_TRY(launch_i8s_slice_rows(kmat, kld, m->np, m->np, w.ns_k, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
+    NNGP_TRY(launch_i8s_scale_sqsum(pk.scale, m->np, pk.scale + m->np_cap, s));
     pk.ns_done = w.ns_k;
     pk.ready = true;
     return 0;
@@ -452,7 +461,10 @@ int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z
     const int64_t np = m->np;
     if (first_residual && use_i8s(m, mp)) {
         const int rc = ensure_i8s(m, mp, m->i8.k);
-        if (rc == 0) return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+        if (rc == 0) {
+            m->i8_used_now = true;
+            return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+        }
         if (rc != 1) return rc;  // 1: no room for the planes -- the float64 pipe below
     }
     NNGP_TRY(launch_gemm_nt_f64(out, np, rhs, np, z, np, m->k64, m->ld, mp, np, np, -1.0, 1.0, s));
@@ -775,6 +787,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
     m->a32_built = false;
     m->i8.k.ready = false;
+    m->i8_checked = m->i8_distrusted = false;
     if (a.sym) {  // whole matrix in one build: the float32 factorisation input falls out of the same epilogue
         if (m->get == NNGP_GET_NNGP) { a.nngp32 = m->a32; a.diag_add_nngp32 = m->reg; }
         else { a.ntk32 = m->a32; a.diag_add_ntk32 = m->reg; }
@@ -924,6 +937,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     m->solve_pending = false;
     m->serving_ready = false;
     m->i8.k.ready = false;
+    m->i8_checked = m->i8_distrusted = false;
     // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
@@ -1139,6 +1153,13 @@ int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_
     return 0;
 }
 
+int nngp_model_residual_floor(nngp_model* m, double* ratio, int32_t* distrusted) {
+    NNGP_REQUIRE(m != nullptr, "residual_floor: NULL model");
+    if (ratio) *ratio = m->i8_checked ? m->i8_floor_ratio : -1.0;
+    if (distrusted) *distrusted = m->i8_distrusted ? 1 : 0;
+    return 0;
+}
+
 int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total) {
     NNGP_REQUIRE(m != nullptr && m->la != nullptr && bytes_total != nullptr, "update_timer_bytes: no timer on this model");
     double b = 0.0;
@@ -1283,6 +1304,8 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         }
     }
     int check_kind = 0;
+    bool i8_check_pending = false;
+    m->i8_used_now = false;
     bool z_valid = false;  // z64 ends up holding the rows K_td (K + reg I)^-1 (to first order): the mean can be corrected through them
     const bool full = (cov_mode == NNGP_COV_FULL);
     const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
@@ -1368,6 +1391,14 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             NNGP_TRY(apply_forward_f32(m, mp, s));
             NNGP_TRY(launch_row_sqsum_f32(m->b32, np, mt, np, var_or_cov, var_or_cov, s));
             check_kind = 4;  // like 1, and r64 already holds the residual of z64
+            if (m->i8_used_now && !m->i8_checked) {  // first int8 residual of this fit: what may the dropped digit pairs have cost?
+                I8Plan pl;
+                NNGP_TRY(i8s_plan(m->i8.ns_z, m->i8.ns_k, m->i8.cut, &pl));
+                NNGP_HIP_CHECK(hipMemsetAsync(m->rows.live + 2, 0, sizeof(unsigned long long), s));
+                NNGP_TRY(launch_i8s_floor_ratio(m->z64, np, mt, np, var_or_cov, pl, m->i8.ns_z, m->i8.ns_k, m->i8.k.scale + m->np_cap,
+                                                reinterpret_cast<unsigned long long*>(m->rows.live + 2), s));
+                i8_check_pending = true;
+            }
             return launch_rows_prepare(m->rows.delta, m->tt_diag, var_or_cov, nullptr, 0, kFlagThr, mt, m->rows.tol,
                                        m->rows.live + 1, s);
         }
@@ -1469,6 +1500,19 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // many CG iterations, or a row's first-order term is too large for its second-order error to be small (k_rows_prepare).
     // Then the rows go on by preconditioned CG until each has converged, and the covariance is formed again.
     // (debug key 6 = 1: fixed sweeps only.)
+    if (i8_check_pending) {
+        // (the host has just waited for the alpha solve: this read-back waits for the covariance kernels enqueued before it, once
+        // per fit -- later predicts on the fit stay asynchronous)
+        NNGP_HIP_CHECK(hipMemcpyAsync(m->rows.host + 2, m->rows.live + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+        NNGP_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(&m->i8_floor_ratio, m->rows.host + 2, sizeof(double));
+        m->i8_checked = true;
+        const double thr = NNGP_KNOB(5) == 56 ? 0.0 : kI8FloorThr;  // key 5 = 56: distrust whatever the estimate says (test)
+        if (!(m->i8_floor_ratio <= thr)) {
+            m->i8_distrusted = true;  // use_i8s is false from here on: the covariance again, on the float64 pipe
+            NNGP_TRY(cov_part());
+        }
+    }
     m->cov_iters = 0;
     m->sweep_est = m->sweep_est_var = -1.0;
     if (check_kind != 0 && NNGP_KNOB(6) != 1) {

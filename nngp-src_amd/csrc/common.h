@@ -200,7 +200,7 @@ struct I8Plan {       // which digit-plane pairs are multiplied, grouped by diag
 };
 struct I8Planes {     // digit planes of one float64 kernel matrix: [6][rows][np_cap] int8, row stride np_cap bytes
     int8_t* planes = nullptr;
-    double* scale = nullptr;     // [np_cap] row scales
+    double* scale = nullptr;     // [np_cap + 1] row scales; the last entry: the sum of their squares (error estimate)
     bool ready = false;          // the planes belong to the current matrix
     int ns_done = 0;             // planes per row they were cut into
 };
@@ -224,6 +224,9 @@ struct I8Work {       // one per model (api.hip): planes of K and of a block of 
 int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl);
 int64_t i8s_chunks(int64_t k);  // K chunks (of <= 16384) a product over k columns is cut into
 int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double* scale, hipStream_t s);
+int launch_i8s_scale_sqsum(const double* scale, int64_t n, double* out, hipStream_t s);
+int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t cols, const double* var, const I8Plan& pl, int nsa, int nsb,
+                           const double* sk2, unsigned long long* out, hipStream_t s);
 int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t cols, int ns, const double* scale_in, double* scale_out,
                           int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s);  // scale_in NULL: scale by the row maxima
 int launch_gemm_nt_i8s(int32_t* partial, int64_t ldc, int64_t slab, const int8_t* a, int64_t lda, int64_t sa, const int8_t* b,

@@ -425,6 +425,55 @@ __global__ __launch_bounds__(256) void k_i8s_combine(double* __restrict__ out, i
     }
 }
 
+
+// out[0] = sum of the squares of n row scales (the planes' scales enter the error estimate below as their root mean square)
+__global__ __launch_bounds__(1024) void k_i8s_scale_sqsum(const double* __restrict__ scale, int64_t n, double* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += scale[i] * scale[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = t;
+    }
+}
+
+// What the dropped digit pairs may have cost a variance that was formed with z . r, r from the int8 product: the dropped pairs of one
+// entry sum N products of two digits (rms 2^12.4) with random signs, so   |z . dr| ~ |z|_2 2^12.4 sqrt(pairs) 256^-(cut+3) sc_z rms_n(sc_k) sqrt(N)
+// = |z|_2 coef sc_z sqrt(sum_n sc_k^2).  One workgroup per row; out[0] = max over the rows of that estimate / var[row] (as the bits of
+// a non-negative double, by atomicMax: order-preserving, deterministic).
+__global__ __launch_bounds__(256) void k_i8s_floor_ratio(const double* __restrict__ z, int64_t ld, int64_t cols, const double* __restrict__ var,
+                                                         double coef, const double* __restrict__ sk2, unsigned long long* out) {
+    __shared__ double red[8];
+    const int64_t r = blockIdx.x;
+    const double* p = z + r * ld;
+    double mx = 0.0, s2 = 0.0;
+    for (int64_t c = 2 * (int64_t)threadIdx.x; c + 1 < cols; c += 512) {
+        const f64x2 v = *reinterpret_cast<const f64x2*>(p + c);
+        mx = fmax(mx, fmax(fabs(v[0]), fabs(v[1])));
+        s2 += v[0] * v[0] + v[1] * v[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, off));
+        s2 += __shfl_xor(s2, off);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; red[4 + (threadIdx.x >> 6)] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        s2 = (red[4] + red[5]) + (red[6] + red[7]);
+        const double est = sqrt(s2) * coef * i8s_scale_of(mx) * sqrt(sk2[0]);
+        const double v = var[r];
+        const double ratio = v > 0.0 ? est / v : (est > 0.0 ? 1.0e300 : 0.0);
+        atomicMax(out, (unsigned long long)__double_as_longlong(ratio));
+    }
+}
+
 }  // namespace
 
 int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double* scale, hipStream_t s) {
@@ -455,6 +504,27 @@ int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t c
 }
 
 // the pairs (ia, ib) with ia + ib <= cut, grouped by diagonal e = ia + ib, LARGEST e first (most pairs first: the long items lead)
+int launch_i8s_scale_sqsum(const double* scale, int64_t n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_i8s_scale_sqsum, dim3(1), dim3(1024), 0, s, scale, n, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// out: one device word, zeroed by the caller; receives the bits of max_r (estimate of |z_r . dr_r|) / var[r] (see k_i8s_floor_ratio)
+int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t cols, const double* var, const I8Plan& pl, int nsa, int nsb,
+                           const double* sk2, unsigned long long* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    // pairs on the first dropped diagonal (+ 2 for the two operands' own truncation at their last plane)
+    int cut = -1;
+    for (int p = 0; p < pl.npairs; ++p) cut = pl.pa[p] + pl.pb[p] > cut ? pl.pa[p] + pl.pb[p] : cut;
+    int dropped = 2;
+    for (int ia = 0; ia < nsa; ++ia) dropped += (cut + 1 - ia >= 0 && cut + 1 - ia < nsb) ? 1 : 0;
+    const double coef = 5404.7 * sqrt((double)dropped) * pow(256.0, -(double)(cut + 3));  // 2^12.4 = 5404.7
+    hipLaunchKernelGGL(k_i8s_floor_ratio, dim3((unsigned)rows), dim3(256), 0, s, z, ld, cols, var, coef, sk2, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl) {
     NNGP_REQUIRE(nsa >= 1 && nsa <= 6 && nsb >= 1 && nsb <= 6 && cut >= 0, "i8s: 1..6 planes per operand");
     if (cut > nsa + nsb - 2) cut = nsa + nsb - 2;

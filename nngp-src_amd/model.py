@@ -249,6 +249,13 @@ class GPModel:
         self._check(self.lib.nngp_model_residual_timer_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ops)))
         return int(n.value), float(ms.value), float(fl.value), float(ops.value)
 
+    def residual_floor(self):
+        """(estimate, distrusted): what the int8 residual's dropped digit pairs may have cost this fit's level-1 variances, relative
+        to them (-1.0 until a predict measured it), and whether the fit was taken off the int8 path for it."""
+        r, d = ctypes.c_double(-1.0), ctypes.c_int32(0)
+        self._check(self.lib.nngp_model_residual_floor(self.handle, ctypes.byref(r), ctypes.byref(d)))
+        return float(r.value), bool(d.value)
+
     def alpha(self):
         import torch
         out = torch.empty((self.n, self.ny), dtype=torch.float64, device=self.device)

@@ -346,6 +346,7 @@ int nngp_model_factor_end(nngp_model* m, void* stream) { (void)m; (void)stream; 
 int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv) { (void)m; (void)a32; (void)ld; (void)dinv; NOT_HERE("nngp_model_factor_buffers"); }
 int nngp_model_prepare_serving(nngp_model* m, void* stream) { (void)m; (void)stream; NOT_HERE("nngp_model_prepare_serving"); }
 int nngp_model_update_timer(nngp_model* m, int32_t enable) { (void)m; (void)enable; NOT_HERE("nngp_model_update_timer"); }
+int nngp_model_residual_floor(nngp_model* m, double* ratio, int32_t* distrusted) { (void)m; if (ratio) *ratio = -1.0; if (distrusted) *distrusted = 0; return 0; }  /* float64 throughout */
 int nngp_model_residual_timer(nngp_model* m, int32_t enable) { (void)m; (void)enable; NOT_HERE("nngp_model_residual_timer"); }
 int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total, double* int8_ops_total) { (void)m; (void)launches; (void)ms_total; (void)flops_total; (void)int8_ops_total; NOT_HERE("nngp_model_residual_timer_read"); }
 int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total) { (void)m; (void)bytes_total; NOT_HERE("nngp_model_update_timer_bytes"); }

@@ -479,6 +479,8 @@ def test_int8_residual_path_against_the_float64_residual():
     mean_i8, var_i8 = model.predict(xt, cov="diag")
     launches, ms, flops, ops = model.residual_timer_read()
     assert launches == 1 and ops == 15 * flops and flops == 2.0 * 384 * 2688 * 2688 and ms > 0.0
+    ratio, distrusted = model.residual_floor()   # the guard's estimate of what the dropped digit pairs cost these variances
+    assert 0.0 < ratio < 1e-5 and not distrusted, ratio
     model.predict(xt[:100], cov="diag")
     assert model.residual_timer_read()[0] == 0   # 128 padded rows: float64 pipe
     model.debug_set(5, 50)
@@ -506,6 +508,21 @@ def test_int8_residual_path_against_the_float64_residual():
     assert full.residual_timer_read()[0] == 0
     np.testing.assert_array_equal(var_f2, var_64)
     full.close()
+    # the guard fires (key 5 = 56: threshold 0): the first predict is redone on the float64 pipe and the fit stays there
+    wary = GPModel(2600, 24, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+    wary.debug_set(5, 56)
+    wary.residual_timer(True)
+    _, var_w = wary.predict(xt, cov="diag")
+    wary.debug_set(5, 0)
+    assert wary.residual_timer_read()[0] == 1 and wary.residual_floor()[1]
+    np.testing.assert_array_equal(var_w, var_64)
+    _, var_w2 = wary.predict(xt, cov="diag")
+    assert wary.residual_timer_read()[0] == 0
+    np.testing.assert_array_equal(var_w2, var_64)
+    wary.fit(x, y)                                  # a new fit is trusted again until measured
+    wary.predict(xt, cov="diag")
+    assert wary.residual_timer_read()[0] == 1 and not wary.residual_floor()[1]
+    wary.close()
     # NTK: the first correction sweep's residual only (one launch per predict), the later residual and W = Z K_dd on the float64 pipe
     ntk = GPModel(2600, 24, [1.0, 1.0], [0.0, 0.0], get="ntk", diag_reg=1e-3, knobs=True).fit(x, y)
     ntk.residual_timer(True)
