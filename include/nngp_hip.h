@@ -284,7 +284,7 @@ int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
  * multiplied exactly (int32 accumulation) and combined in float64.  Error: ~256^-(cut+2) and 256^-slices of (row maximum of A) x
  * (row maximum of B) x K per entry -- with 5 x 5 planes and cut = 4, about 2^-40 of that bound.  This is the residual product of the
  * posterior (reference: predict_fn(..., compute_cov=True), train.py:157-158) as a test / integration primitive: it allocates and
- * frees its own planes.  M, N multiples of 128, any K >= 1; lda, ldb even; 2 <= slices <= 6.  Cin may be C or NULL (beta = 0). */
+ * frees its own planes.  M, N multiples of 128, any K >= 1; lda, ldb even; 2 <= slices <= 7 (7 x 7 planes with cut 6, 28 products, is float64 grade proper).  Cin may be C or NULL (beta = 0). */
 int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                      const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                      int32_t slices_a, int32_t slices_b, int32_t cut, void* stream);

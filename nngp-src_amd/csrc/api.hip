@@ -167,7 +167,7 @@ struct nngp_model {
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
         if (ev_i8) (void)hipEventDestroy(ev_i8);
-        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.zplanes);
+        dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes);
         for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
@@ -336,11 +336,17 @@ bool use_i8s(const nngp_model* m, int64_t mp) {
     return m->np >= 2048 && mp >= 256 && NNGP_KNOB(5) != 50;
 }
 
-#ifdef NNGP_TIMING_KNOBS
-constexpr int kI8MaxPlanes = 6;  // the knobs build can try 6 x 6 planes (key 5 = 52)
-#else
-constexpr int kI8MaxPlanes = 5;
-#endif
+// Two grades of the product.  COARSE: 5 x 5 planes, pairs with ia + ib <= 4 (15 exact plane products; error ~2^-32 sqrt(N) of the row
+// maxima) -- for a FIRST residual.  FINE: 7 x 7 planes, ia + ib <= 6 (28 products; ~2^-48 sqrt(N): what the float64 matrix pipe
+// delivers) -- for the later residuals and the NTK's W = Z K_dd, where the coarse floor would show (see residual_rows); 28 products
+// still cost 3/4 of the float64 product at N = 32768.  A model that will ask for FINE products (NTK fits, covariance levels >= 2)
+// has its kernel matrix cut into 7 planes once; coarse products then read the first five of them.
+enum { I8_COARSE = 0, I8_FINE = 1 };
+constexpr int kI8FinePlanes = 7, kI8FineCut = 6;
+
+// FINE pays later than COARSE (28 against 15 products): from N = 4096 and four 128-row tiles of right-hand sides on.  Debug key 5 = 57: off.
+bool use_i8s_fine(const nngp_model* m, int64_t mp) { return use_i8s(m, mp) && m->np >= 4096 && mp >= 512 && NNGP_KNOB(5) != 57; }
+int i8s_planes_policy(const nngp_model* m) { return (m->get == NNGP_GET_NTK || m->var_refine >= 2) && NNGP_KNOB(5) != 57 ? kI8FinePlanes : 5; }
 
 template <typename T>
 static bool soft_alloc(T** p, int64_t count) {  // false (and no sticky error) when the device has no room
@@ -352,26 +358,33 @@ static bool soft_alloc(T** p, int64_t count) {  // false (and no sticky error) w
     return false;
 }
 
-// Workspace of the int8 residual path: 5 N^2 bytes of digit planes + the planes and exact plane products of one block of rows.
-// Returns 1 -- and the model stays on the float64 pipe from then on -- when the device has no room for them (a kernel matrix that
-// fills most of the 288 GB leaves none): the int8 path is an accelerator, not a requirement.
-int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
+// Workspace of the int8 path: `planes` N^2 bytes of digit planes of the kernel matrix `pk` + the planes and exact plane products of
+// one block of rows.  Returns 1 -- and the model stays on the float64 pipe from then on -- when the device has no room for them (a
+// kernel matrix that fills most of the 288 GB leaves none): the int8 path is an accelerator, not a requirement.
+int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk, int planes) {
     I8Work& w = m->i8;
     if (NNGP_KNOB(5) == 51) { w.ns_k = w.ns_z = 4; w.cut = 3; }
     else if (NNGP_KNOB(5) == 52) { w.ns_k = w.ns_z = 6; w.cut = 5; }
     else { w.ns_k = w.ns_z = 5; w.cut = 4; }
+    if (planes < w.ns_k) planes = w.ns_k;
     w.k_rows = round_up(m->np_cap, 256);
     auto give_up = [&]() -> int {
-        dev_free(pk.planes); dev_free(pk.scale); dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
-        pk.ready = false;
+        dev_free(m->i8.k.planes); dev_free(m->i8.k.scale); dev_free(m->i8.aux.planes); dev_free(m->i8.aux.scale);
+        dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
+        m->i8.k.ready = m->i8.aux.ready = false;
+        m->i8.k.alloc_planes = m->i8.aux.alloc_planes = 0;
         w.z_rows = 0;
+        w.z_planes = 0;
         m->i8_unavailable = true;
         return 1;
     };
-    if (pk.planes == nullptr) {
+    if (pk.alloc_planes < planes) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
-        if (!soft_alloc(&pk.planes, kI8MaxPlanes * w.k_rows * m->np_cap) || !soft_alloc(&pk.scale, m->np_cap + 1)) return give_up();
-        NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(kI8MaxPlanes * w.k_rows * m->np_cap)));
+        dev_free(pk.planes); dev_free(pk.scale);
+        pk.alloc_planes = 0;
+        if (!soft_alloc(&pk.planes, planes * w.k_rows * m->np_cap) || !soft_alloc(&pk.scale, m->np_cap + 1)) return give_up();
+        NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(planes * w.k_rows * m->np_cap)));
+        pk.alloc_planes = planes;
         pk.ready = false;
     }
     if (w.counters == nullptr) {
@@ -379,56 +392,63 @@ int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk) {
         NNGP_HIP_CHECK(hipMemset(w.counters, 0, 16 * sizeof(int)));
     }
     const int64_t rows = mp < kI8RowBlock ? mp : kI8RowBlock;
-    if (rows > w.z_rows) {
+    if (rows > w.z_rows || planes > w.z_planes) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
+        const int64_t nr = rows > w.z_rows ? rows : w.z_rows;
+        const int np_ = planes > w.z_planes ? planes : w.z_planes;
         w.z_rows = 0;
-        if (!soft_alloc(&w.zplanes, kI8MaxPlanes * (rows + 256) * m->np_cap) || !soft_alloc(&w.zscale, rows) ||
-            !soft_alloc(&w.partial, i8s_chunks(m->np_cap) * kI8MaxPlanes * rows * m->np_cap))  // diagonals = cut + 1 <= planes
+        w.z_planes = 0;
+        if (!soft_alloc(&w.zplanes, np_ * (nr + 256) * m->np_cap) || !soft_alloc(&w.zscale, nr) ||
+            !soft_alloc(&w.partial, i8s_chunks(m->np_cap) * np_ * nr * m->np_cap))  // diagonals = cut + 1 <= planes
             return give_up();
-        NNGP_HIP_CHECK(hipMemset(w.zplanes, 0, (size_t)(kI8MaxPlanes * (rows + 256) * m->np_cap)));
-        w.z_rows = rows;
+        NNGP_HIP_CHECK(hipMemset(w.zplanes, 0, (size_t)(np_ * (nr + 256) * m->np_cap)));
+        w.z_rows = nr;
+        w.z_planes = np_;
     }
     return 0;
 }
 
-// the digit planes of a kernel matrix.  It is positive semi-definite: row i is bounded by sqrt(K_ii max_j K_jj) -- no pass over the
-// matrix for the scales
+// the digit planes of a kernel matrix (as many as were allocated for it).  It is positive semi-definite: row i is bounded by
+// sqrt(K_ii max_j K_jj) -- no pass over the matrix for the scales
 int i8s_cut_planes(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, hipStream_t s) {
     I8Work& w = m->i8;
     NNGP_TRY(launch_i8s_diag_bound_scale(kmat, kld, m->np, pk.scale, s));
-    NNGP_TRY(launch_i8s_slice_rows(kmat, kld, m->np, m->np, w.ns_k, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
+    NNGP_TRY(launch_i8s_slice_rows(kmat, kld, m->np, m->np, pk.alloc_planes, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
     NNGP_TRY(launch_i8s_scale_sqsum(pk.scale, m->np, pk.scale + m->np_cap, s));
-    pk.ns_done = w.ns_k;
+    pk.ns_done = pk.alloc_planes;
     pk.ready = true;
     return 0;
 }
 
-// out [mp, np] = beta cin + alpha z Kmat + gamma z on the int8 pipe, float64 grade; Kmat: a symmetric positive semi-definite
-// [np, np] kernel matrix (k64, or kaux64 beside an NTK fit) whose digit planes are kept in pk.
-// The planes (13 N^2 bytes of HBM traffic to cut: 2.7 ms at N = 32768) are cut once per change of the matrix: by nngp_model_predict
-// on the solve stream beside its first blocked solves (-0.8 ms against stream order at N = 32768), else here in stream order.
-// Measured and dropped (profiles/r3_i8s_slicing_placement.json): slicing beside the FACTORISATION on a second stream costs the
-// Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768 small
-// workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on a
-// CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
+// out [mp, np] = beta cin + alpha z Kmat + gamma z on the int8 pipe; Kmat: a symmetric positive semi-definite [np, np] kernel matrix
+// (k64, or kaux64 beside an NTK fit) whose digit planes are kept in pk (workspace: ensure_i8s, by the caller).
+// The planes (13 N^2 bytes of HBM traffic to cut 5 of them: 2.7 ms at N = 32768) are cut once per change of the matrix: by
+// nngp_model_predict on the solve stream beside its first blocked solves (-0.8 ms against stream order at N = 32768), else here in
+// stream order.  Measured and dropped (profiles/r3_i8s_slicing_placement.json): slicing beside the FACTORISATION on a second stream
+// costs the Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768
+// small workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on
+// a CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
 int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, double* out, const double* cin, double beta,
-                     double alpha, const double* z, double gamma, int64_t mp, hipStream_t s) {
+                     double alpha, const double* z, double gamma, int64_t mp, hipStream_t s, int grade) {
     const int64_t np = m->np;
-    I8Work& w = m->i8;  // workspace: ensure_i8s, by the caller
-    if (!pk.ready || pk.ns_done != w.ns_k) {
+    I8Work& w = m->i8;
+    const int ns_z = grade == I8_FINE ? kI8FinePlanes : w.ns_z, ns_k = grade == I8_FINE ? kI8FinePlanes : w.ns_k;
+    const int cut = grade == I8_FINE ? kI8FineCut : w.cut;
+    NNGP_REQUIRE(pk.alloc_planes >= ns_k && w.z_planes >= ns_z, "i8s_product_rows: workspace for %d planes missing", ns_k);
+    if (!pk.ready || pk.ns_done < ns_k) {
         NNGP_TRY(i8s_cut_planes(m, pk, kmat, kld, s));
-    } else if (m->i8_k_pending) {  // cut on the solve stream at the start of this predict
+    } else if (&pk == &m->i8.k && m->i8_k_pending) {  // cut on the solve stream at the start of this predict
         NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_i8, 0));
     }
-    m->i8_k_pending = false;
+    if (&pk == &m->i8.k) m->i8_k_pending = false;
     I8Plan pl;
-    NNGP_TRY(i8s_plan(w.ns_z, w.ns_k, w.cut, &pl));
+    NNGP_TRY(i8s_plan(ns_z, ns_k, cut, &pl));
     const int64_t nchunk = i8s_chunks(np);
     for (int64_t r0 = 0; r0 < mp; r0 += kI8RowBlock) {
         const int64_t mb = mp - r0 < kI8RowBlock ? mp - r0 : kI8RowBlock;
         const int64_t slab = mb * np;
-        NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, w.ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
+        NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
         const bool timed = w.timed && w.t_count < I8Work::kMaxTimed;
         if (timed) {
             const int t = w.t_count;
@@ -451,19 +471,19 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
 }
 
 // out [mp, np] = rhs - z (K + reg I) for z = z64 (or another [mp, np] block).
-// first_residual: z comes straight from the float32 solves, so the residual is ~1e-4 of rhs and the int8 product's error floor
-// (2^-32 sqrt(N) of the row maxima with 5 x 5 planes, ~1e-3 of such a residual) is harmless: the NNGP level-1 variance moves by
-// 2e-7 (N = 32768) .. 7e-7 (ill-conditioned sweep case), a first correction sweep loses nothing.  Every LATER residual is ~1e-8 of
-// rhs and needs the float64 pipe proper -- measured with the int8 product there (scripts/i8s_hard_case.py): NTK variances off by
-// 3e-5 .. 2e-4 (first order in the rows' error) against 1e-8, NNGP level 2 at 1e-7 instead of 1e-8, the explicit inverse of the
-// serving mode stuck four digits short of float64 (serving variances 4e-3 off).
+// first_residual: z comes straight from the float32 solves, so the residual is ~1e-4 of rhs and the COARSE product's error floor
+// (2^-32 sqrt(N) of the row maxima, ~1e-3 of such a residual) is harmless: the NNGP level-1 variance moves by 2e-7 (N = 32768) ..
+// 7e-7 (ill-conditioned sweep case), a first correction sweep loses nothing.  Every LATER residual is ~1e-8 of rhs and needs float64
+// grade proper -- measured with the coarse product there (scripts/i8s_hard_case.py): NTK variances off by 3e-5 .. 2e-4 (first order
+// in the rows' error) against 1e-8, NNGP level 2 at 1e-7 instead of 1e-8, the explicit inverse of the serving mode stuck four digits
+// short of float64 (serving variances 4e-3 off).  Those take the FINE product where it pays, else the float64 pipe.
 int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s, bool first_residual) {
     const int64_t np = m->np;
-    if (first_residual && use_i8s(m, mp)) {
-        const int rc = ensure_i8s(m, mp, m->i8.k);
+    if (first_residual ? use_i8s(m, mp) : use_i8s_fine(m, mp)) {
+        const int rc = ensure_i8s(m, mp, m->i8.k, first_residual ? i8s_planes_policy(m) : kI8FinePlanes);
         if (rc == 0) {
-            m->i8_used_now = true;
-            return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s);
+            if (first_residual) m->i8_used_now = true;
+            return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s, first_residual ? I8_COARSE : I8_FINE);
         }
         if (rc != 1) return rc;  // 1: no room for the planes -- the float64 pipe below
     }
@@ -1292,9 +1312,9 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // traffic) are cut on the solve stream while this stream runs the first two blocked solves, whose launches leave most of the
     // chip's bandwidth and, between them, its compute units idle.  (debug key 5 = 53: in stream order where they are first needed)
     if (cov_mode != NNGP_COV_NONE && m->var_refine >= 1 && use_i8s(m, mp) && !(m->serving_ready && !is_ntk) && NNGP_KNOB(5) != 53) {
-        const int rc_i8 = ensure_i8s(m, mp, m->i8.k);
+        const int rc_i8 = ensure_i8s(m, mp, m->i8.k, i8s_planes_policy(m));
         if (rc_i8 != 0 && rc_i8 != 1) return rc_i8;
-        if (rc_i8 == 0 && (!m->i8.k.ready || m->i8.k.ns_done != m->i8.ns_k)) {
+        if (rc_i8 == 0 && !m->i8.k.ready) {
             if (m->ev_i8 == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_i8, hipEventDisableTiming));
             NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, s));  // K is complete; earlier readers of the planes are behind us
             NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_i8, 0));
@@ -1310,7 +1330,14 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     const bool full = (cov_mode == NNGP_COV_FULL);
     const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
     auto ntk_finish = [&]() -> int {    // from z64 = Theta_td (Theta_dd + reg I)^-1; K_tt already in ktt64 (full)
-        NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));  // W = Z K_dd (float64 proper: its error is the variance's)
+        // W = Z K_dd: its error is the variance's -- float64 grade proper (the FINE product where it pays)
+        int rc_w = use_i8s_fine(m, mp) ? ensure_i8s(m, mp, m->i8.aux, kI8FinePlanes) : 1;
+        if (rc_w == 0) {
+            NNGP_TRY(i8s_product_rows(m, m->i8.aux, m->kaux64, np, m->r64, nullptr, 0.0, 1.0, m->z64, 0.0, mp, s, I8_FINE));
+        } else {
+            if (rc_w != 1) return rc_w;
+            NNGP_TRY(launch_gemm_nt_f64(m->r64, np, nullptr, 0, m->z64, np, m->kaux64, np, mp, np, np, 1.0, 0.0, s));
+        }
         if (!full)  // var_i = K_tt,ii + z_i . (w_i - 2 k_i)
             return launch_rowdot_f64(m->z64, ntk_cross, -2.0, m->r64, np, mt, np, m->tt_diag, 1.0, var_or_cov, s);
         NNGP_TRY(launch_axpby_mat(m->r64, 1.0, ntk_cross, -1.0, np, mp, np, s));  // G = W - K_td
@@ -1468,6 +1495,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         NNGP_TRY(launch_kernel_build(a, m->arch, s));
         NNGP_TRY(launch_zero_pad_f64(m->kaux64, np, n, np, s));
         m->aux_ready = true;
+        m->i8.aux.ready = false;
     }
     const double* ktd_n = m->kaux64;  // NNGP cross kernel; x_test=None: K_dd itself
     if (!on_train) {

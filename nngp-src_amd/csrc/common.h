@@ -203,13 +203,15 @@ struct I8Planes {     // digit planes of one float64 kernel matrix: [6][rows][np
     double* scale = nullptr;     // [np_cap + 1] row scales; the last entry: the sum of their squares (error estimate)
     bool ready = false;          // the planes belong to the current matrix
     int ns_done = 0;             // planes per row they were cut into
+    int alloc_planes = 0;        // planes there is room for
 };
-struct I8Work {       // one per model (api.hip): planes of K and of a block of right-hand-side rows
-    I8Planes k;
+struct I8Work {       // one per model (api.hip): planes of K (and of the NNGP kernel beside an NTK fit), of a block of right-hand-side rows
+    I8Planes k, aux;
     int64_t k_rows = 0;          // rows per plane (np_cap up to the next multiple of 256)
     int8_t* zplanes = nullptr;   // [6][z_rows + 256][np_cap]
     double* zscale = nullptr;    // [z_rows]
     int64_t z_rows = 0;
+    int z_planes = 0;            // planes zplanes / partial have room for
     int32_t* partial = nullptr;  // [chunks][diagonals][z_rows][np_cap] exact plane products
     int* counters = nullptr;     // work counters of the persistent grid
     int ns_k = 5, ns_z = 5, cut = 4;

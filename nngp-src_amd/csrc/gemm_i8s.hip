@@ -1,7 +1,7 @@
 // Float64-grade NT product on the 8-bit-integer matrix pipe of gfx950 ("sliced" operands, Ozaki-style):
 //     C[M,N] = beta*Cin + alpha * A[M,K] * B[N,K]^T + gamma*G        (all float64 in HBM)
 // Every row of A and of B is scaled by its own power of two sc (|x| / sc <= 126/256) and written as `ns` balanced base-256 digits
-//     x / sc = sum_{i < ns} dig_i(x) 256^-(i+1),   dig_i in [-128, 127]   (fixed point of 8 ns bits, rounded to nearest once),
+//     x / sc = sum_{i < ns} dig_i(x) 256^-(i+1),   dig_i in [-128, 127]   (fixed point of 8 ns bits, ns <= 7, rounded to nearest once),
 // one int8 plane per digit.  The product of two planes is EXACT on v_mfma_i32_16x16x64_i8 (int32 accumulation, no rounding), so
 //     A B^T = sc_a sc_b sum_{i,j} 256^-(i+j+2) (A_i B_j^T),
 // and only the pairs with i + j <= cut are formed: the dropped ones are below 256^-(cut+2) ~ 2^-48 (cut = 4) of the row scales.
@@ -488,16 +488,17 @@ int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t c
                           int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s) {
     if (rows <= 0) return 0;
     const int64_t kp = round_up(cols, 128);
-    NNGP_REQUIRE(ns >= 2 && ns <= 6 && ld % 2 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 15) == 0 && ldp >= kp &&
+    NNGP_REQUIRE(ns >= 2 && ns <= 7 && ld % 2 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 15) == 0 && ldp >= kp &&
                      ldp % 16 == 0 && pstride % 16 == 0 && rows < 2147483647LL && (scale_in != nullptr || scale_out != nullptr),
-                 "i8s_slice_rows: 2..6 planes, 16-byte aligned operands");
+                 "i8s_slice_rows: 2..7 planes, 16-byte aligned operands");
     const dim3 g((unsigned)rows);
     switch (ns) {
         case 2: hipLaunchKernelGGL(k_i8s_slice_rows<2>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
         case 3: hipLaunchKernelGGL(k_i8s_slice_rows<3>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
         case 4: hipLaunchKernelGGL(k_i8s_slice_rows<4>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
         case 5: hipLaunchKernelGGL(k_i8s_slice_rows<5>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
-        default: hipLaunchKernelGGL(k_i8s_slice_rows<6>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
+        case 6: hipLaunchKernelGGL(k_i8s_slice_rows<6>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
+        default: hipLaunchKernelGGL(k_i8s_slice_rows<7>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
     }
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -526,7 +527,7 @@ int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t co
 }
 
 int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl) {
-    NNGP_REQUIRE(nsa >= 1 && nsa <= 6 && nsb >= 1 && nsb <= 6 && cut >= 0, "i8s: 1..6 planes per operand");
+    NNGP_REQUIRE(nsa >= 1 && nsa <= 7 && nsb >= 1 && nsb <= 7 && cut >= 0, "i8s: 1..7 planes per operand");
     if (cut > nsa + nsb - 2) cut = nsa + nsb - 2;
     *pl = I8Plan{};
     int np = 0;

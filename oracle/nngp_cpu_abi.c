@@ -384,7 +384,7 @@ int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
                      int32_t cut, void* stream) {
     (void)stream;
     REQUIRE(a != NULL && b != NULL && c != NULL && m > 0 && n > 0 && k > 0, "gemm_nt_i8s: bad arguments");
-    REQUIRE(slices_a >= 2 && slices_a <= 6 && slices_b >= 2 && slices_b <= 6 && cut >= 0, "gemm_nt_i8s: 2..6 planes per operand");
+    REQUIRE(slices_a >= 2 && slices_a <= 7 && slices_b >= 2 && slices_b <= 7 && cut >= 0, "gemm_nt_i8s: 2..7 planes per operand");
     if (cut > slices_a + slices_b - 2) cut = slices_a + slices_b - 2;
     int8_t* da = (int8_t*)malloc((size_t)(m * slices_a * k));
     int8_t* db = (int8_t*)malloc((size_t)(n * slices_b * k));

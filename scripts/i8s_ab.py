@@ -1,5 +1,6 @@
-"""A/B of the int8 residual path at a bench config (knobs library): fit / predict times and the variances with the float64 residual
-product (key 5 = 50), the default 5 x 5 digit planes with cut 4, and 4 x 4 / 6 x 6 planes (keys 51 / 52).  Earlier forms of this
+"""A/B of the int8 residual path at a bench config (knobs library): fit / predict times and the variances with every product on the
+float64 pipe (key 5 = 50), the default (COARSE int8 first residual, FINE int8 later products), the coarse product only (key 5 = 57) and
+the planes of K cut in stream order instead of beside the first solves (key 5 = 53).  Earlier forms of this
 script also timed WHERE the planes of K are cut (beside the Cholesky on a priority stream, late in it, on CU-masked streams):
 profiles/r3_i8s_slicing_placement.json."""
 import sys, json, time
@@ -23,7 +24,7 @@ def step():
     return (t1 - t0) * 1e3, (t2 - t1) * 1e3, mean, var
 out = {"config": cfg}
 ref = None
-for name, key in (("f64", 50), ("i8s_planes_beside_the_solves", 0), ("i8s_planes_in_stream_order", 53), ("i8s_planes_beside_the_solves_again", 0)):
+for name, key in (("f64", 50), ("i8s_default", 0), ("i8s_coarse_first_residual_only", 57), ("i8s_planes_in_stream_order", 53)):
     lib.nngp_debug_set(5, key)
     for _ in range(2): step()
     ts = [step() for _ in range(4)]
