@@ -126,7 +126,7 @@ struct nngp_model {
     // float64 pipe and the fit stays there.
     bool i8_checked = false, i8_distrusted = false, i8_used_now = false;
     double i8_floor_ratio = -1.0;
-    bool i8_suspended = false;  // prepare_serving: the explicit inverse is refined against float64 residuals proper
+    bool i8_suspended = false;   // prepare_serving: the explicit inverse is refined against residuals of the float64 pipe itself  // prepare_serving: the explicit inverse is refined against float64 residuals proper
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
     // Diagonal shift of the float32 factor's input.  = reg, unless the float32 factorisation of K + reg I broke down
@@ -479,11 +479,12 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
 // short of float64 (serving variances 4e-3 off).  Those take the FINE product where it pays, else the float64 pipe.
 int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s, bool first_residual) {
     const int64_t np = m->np;
-    if (first_residual ? use_i8s(m, mp) : use_i8s_fine(m, mp)) {
-        const int rc = ensure_i8s(m, mp, m->i8.k, first_residual ? i8s_planes_policy(m) : kI8FinePlanes);
+    const bool coarse = first_residual;
+    if (coarse ? use_i8s(m, mp) : use_i8s_fine(m, mp)) {
+        const int rc = ensure_i8s(m, mp, m->i8.k, coarse ? i8s_planes_policy(m) : kI8FinePlanes);
         if (rc == 0) {
-            if (first_residual) m->i8_used_now = true;
-            return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s, first_residual ? I8_COARSE : I8_FINE);
+            if (coarse) m->i8_used_now = true;
+            return i8s_product_rows(m, m->i8.k, m->k64, m->ld, out, rhs, 1.0, -1.0, z, -m->reg, mp, s, coarse ? I8_COARSE : I8_FINE);
         }
         if (rc != 1) return rc;  // 1: no room for the planes -- the float64 pipe below
     }
@@ -1251,8 +1252,10 @@ int nngp_model_prepare_serving(nngp_model* m, void* stream) {
     const bool weak = m->iters >= 8 || m->reg_fac > m->reg;
     const double shift = (m->reg > 0.0 && m->reg_fac > m->reg) ? sqrt(m->reg_fac / m->reg) : 1.0;
     // The serving predictions SQUARE the inverse's error (second-order formula) on top of a cancellation of 1e3 .. 1e6: the
-    // inverse has to converge to float64 accuracy proper, and the int8 residual's floor (2^-32 of the row maxima) stops the sweeps
-    // four digits short of it -- measured: 4e-3 in the serving variances at N = 2500 against 1e-7 (scripts/i8s_hard_case.py).
+    // inverse has to converge to float64 accuracy proper, and the COARSE int8 residual's floor (2^-32 of the row maxima) stops the
+    // sweeps four digits short of it -- measured: 4e-3 in the serving variances at N = 2500 against 1e-7 (scripts/i8s_hard_case.py).
+    // Nor the FINE product: an inverse refined against it serves variances at 1e-9 .. 6e-9 of level 3 where the float64 pipe's
+    // reaches 2e-11 .. 5e-11, for 10-20 % of the build time (scripts/i8s_serving_build.py).
     struct Suspend { bool& f; explicit Suspend(bool& b) : f(b) { f = true; } ~Suspend() { f = false; } } suspend(m->i8_suspended);
     for (int64_t r0 = 0; r0 < n; r0 += blk) {
         const int64_t rows = (n - r0 < blk) ? n - r0 : blk, rp = round_up(rows, TB);
