@@ -118,6 +118,8 @@ struct nngp_model {
     // Sliced int8 copies of K for the residual products of the covariance (gemm_i8s.hip): allocated and cut by the first predict
     // that takes that path, cut again after every change of K.
     I8Work i8{};
+    hipEvent_t ev_gate = nullptr;  // start of the covariance's int8 plane products on the caller's stream: the deferred alpha CG waits for it
+    bool gate_recorded = false;
     hipEvent_t ev_i8 = nullptr;  // the planes of K were cut on the solve stream (beside the first blocked solves of a predict)
     bool i8_k_pending = false;   // ... and the consumer has not waited for that yet
     bool i8_unavailable = false; // no room for its workspace on this device: float64 pipe from then on
@@ -167,6 +169,7 @@ struct nngp_model {
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
         if (ev_i8) (void)hipEventDestroy(ev_i8);
+        if (ev_gate) (void)hipEventDestroy(ev_gate);
         dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes);
         for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
@@ -449,6 +452,15 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
         const int64_t mb = mp - r0 < kI8RowBlock ? mp - r0 : kI8RowBlock;
         const int64_t slab = mb * np;
         NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
+        if (r0 == 0 && grade == I8_COARSE && !m->gate_recorded && NNGP_KNOB(2) != 8 && NNGP_KNOB(2) != 9) {
+            // The deferred alpha CG (solve stream) starts HERE, not with the blocked solves before this product: its hundreds of small
+            // GEMV launches settle on compute units between the solves' persistent split-float16 launches (which need a whole unit's
+            // LDS) and cost them 3.7 ms at N = 32768 (scripts/cov_alone.py); beside this one long launch they fit the wave slots and
+            // the 32 KB of LDS it leaves.
+            if (m->ev_gate == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_gate, hipEventDisableTiming));
+            NNGP_HIP_CHECK(hipEventRecord(m->ev_gate, s));
+            m->gate_recorded = true;
+        }
         const bool timed = w.timed && w.t_count < I8Work::kMaxTimed;
         if (timed) {
             const int t = w.t_count;
@@ -466,6 +478,11 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
         }
         NNGP_TRY(launch_i8s_combine(out + r0 * np, np, cin ? cin + r0 * np : nullptr, np, beta, alpha, z + r0 * np, np, gamma, w.partial, np,
                                     slab, (int)nchunk, pl.ndiag, w.zscale, pk.scale, mb, np, s));
+    }
+    if (grade == I8_COARSE && !m->gate_recorded && NNGP_KNOB(2) == 9) {  // timing experiment: the CG starts when the product has ended
+        if (m->ev_gate == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_gate, hipEventDisableTiming));
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_gate, s));
+        m->gate_recorded = true;
     }
     return 0;
 }
@@ -1059,6 +1076,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
         note_solve(m, it, rr);
     } else {
         NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_ready, 0));
+        if (m->gate_recorded) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_gate, 0));  // see i8s_product_rows
         for (int c = 0; c < m->ny; ++c) {
             NNGP_TRY(launch_strided_copy_f64(m->y + c, m->ny, m->pcg.bcol, 1, m->n, s));
             int it = 0;
@@ -1329,6 +1347,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     int check_kind = 0;
     bool i8_check_pending = false;
     m->i8_used_now = false;
+    m->gate_recorded = false;
     bool z_valid = false;  // z64 ends up holding the rows K_td (K + reg I)^-1 (to first order): the mean can be corrected through them
     const bool full = (cov_mode == NNGP_COV_FULL);
     const double* ntk_cross = nullptr;  // NNGP cross kernel of the NTK covariance
