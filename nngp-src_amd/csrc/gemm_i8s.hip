@@ -4,7 +4,8 @@
 //     x / sc = sum_{i < ns} dig_i(x) 256^-(i+1),   dig_i in [-128, 127]   (fixed point of 8 ns bits, ns <= 7, rounded to nearest once),
 // one int8 plane per digit.  The product of two planes is EXACT on v_mfma_i32_16x16x64_i8 (int32 accumulation, no rounding), so
 //     A B^T = sc_a sc_b sum_{i,j} 256^-(i+j+2) (A_i B_j^T),
-// and only the pairs with i + j <= cut are formed: the dropped ones are below 256^-(cut+2) ~ 2^-48 (cut = 4) of the row scales.
+// and only the pairs with i + j <= cut are formed: the dropped ones are below 256^-(cut+3) 2^14 ~ 2^-42 (cut = 4) of the row scales
+// per k.  Two grades are used (api.hip): 5 x 5 planes with cut 4 (15 products) and 7 x 7 with cut 6 (28: float64 grade proper).
 // All pairs of one "diagonal" i + j = e share a weight and ONE int32 accumulator; K is cut into chunks of <= 16384 so that no
 // accumulator can overflow (7 pairs x 16384 k x 2^14 < 2^31).  A second kernel adds the diagonals in float64 (Horner in 2^-8,
 // fixed order: bitwise reproducible), applies the row scales and fuses beta*Cin and gamma*G.
@@ -12,7 +13,7 @@
 // Why: the posterior's residual product R = K_td - Z (K + reg I) (reference: predict_fn(..., compute_cov=True),
 // train.py:157-158) cancels to ~1e-4 of terms 1e3..1e5 larger, so nothing below float64 GRADE works -- but the float64 matrix
 // pipe runs at 78.6 TF/s and the int8 pipe at ~5 POPS: 15 exact slice products (5 x 5 digits, cut 4: 40 bits below each row's
-// maximum; scripts/ozaki8_check.py) cost a third of one float64 product.  M = 1024, N = K = 32768: 32-35 ms -> see DESIGN.md.
+// maximum; scripts/ozaki8_check.py) cost a third of one float64 product.  M = 1024, N = K = 32768: 32-35 ms -> 12.5.
 //
 // Kernel k_gemm_nt_i8s: the tile machinery of k_gemm_nt_h3v2 (gemm_h3.hip) on the int8 pipe.  512 threads = 8 waves (2 x 4), tile
 // 256 x 256, wave sub-tile 128 x 64 = 8 x 4 accumulators of v_mfma_i32_16x16x64_i8 with the operands swapped (a lane's 4 results =
