@@ -293,6 +293,20 @@ def test_c_abi_error_codes_instead_of_crashes():
     assert lib.nngp_model_predict(h, p(x[:16]), 16, 1, p(out), p(var), s) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and (var > 0).all()
+    # the int8 product's entry point and the residual diagnostics
+    a = torch.rand((128, 64), dtype=torch.float64, device=dev)
+    c = torch.empty((128, 128), dtype=torch.float64, device=dev)
+    for call, needle in [
+        (lambda: lib.nngp_gemm_nt_i8s(p(c), 128, None, 0, p(a), 64, p(a), 64, 100, 128, 64, 1.0, 0.0, 5, 5, 4, s), "multiples of"),
+        (lambda: lib.nngp_gemm_nt_i8s(p(c), 128, None, 0, p(a), 64, p(a), 64, 128, 128, 64, 1.0, 0.0, 9, 5, 4, s), "planes per operand"),
+        (lambda: lib.nngp_gemm_nt_i8s(p(c), 128, None, 0, None, 64, p(a), 64, 128, 128, 64, 1.0, 0.0, 5, 5, 4, s), "multiples of"),
+        (lambda: lib.nngp_model_residual_floor(None, None, None), "NULL model"),
+        (lambda: lib.nngp_model_residual_timer(None, 1), "NULL model"),
+    ]:
+        ok, info = failed(call(), needle)
+        assert ok, info
+    ratio, off = ctypes.c_double(0.0), ctypes.c_int32(7)
+    assert lib.nngp_model_residual_floor(h, ctypes.byref(ratio), ctypes.byref(off)) == 0 and ratio.value == -1.0 and off.value == 0
     lib.nngp_model_destroy(h)
 
 
