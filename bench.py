@@ -445,7 +445,7 @@ def main():
             "value": round(fl["total"] / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (Cholesky products as split f16 x3, f32 accumulate; f64 build/CG/means)", "data": "synthetic",
+            "dtype": "f32 (Cholesky products as split f16 x3, f32 accumulate; f64 build/CG/means; the posterior's float64-grade residual as exact int8 digit-plane products)", "data": "synthetic",
             "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": m,
                        "parallelism": ("single GPU" if world == 1 else
                                        ("row-block kernel shard x%d + one in-place all-gather, %s, replicated alpha solve, test rows sharded"
