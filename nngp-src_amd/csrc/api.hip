@@ -633,7 +633,7 @@ int nngp_version(void) { return NNGP_ABI_VERSION; }
 
 #ifdef NNGP_TIMING_KNOBS
 int nngp_debug_set(int32_t key, int32_t value) {
-    NNGP_REQUIRE(key >= 0 && key < 8, "debug_set: key out of range");
+    NNGP_REQUIRE(key >= 0 && key < 16, "debug_set: key out of range");
     g_knobs[key].store(value, std::memory_order_relaxed);
     return 0;
 }
@@ -764,8 +764,8 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         rc = dev_alloc(&m->split.planes, ncols * m->split.col_stride);
         if (rc == 0) rc = dev_alloc(&m->split.counters, 16);
         if (rc == 0 && hipMemset(m->split.counters, 0, 16 * sizeof(int)) != hipSuccess) rc = -1;
-        if (rc == 0) rc = dev_alloc(&m->split.ldiag, kLookAheadNb * kLookAheadNb * 4);
-        if (rc == 0) rc = dev_alloc(&m->split.dfrag, kLookAheadNb * 128);
+        if (rc == 0) rc = dev_alloc(&m->split.ldiag, 2 * kLookAheadNb * kLookAheadNb * 4);
+        if (rc == 0) rc = dev_alloc(&m->split.dfrag, 2 * kLookAheadNb * 128);
     }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {

@@ -35,8 +35,11 @@ void set_error(const char* fmt, ...);
 //      order instead of deferred
 //   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
 //   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
+//   8  round 4, grouped Cholesky: 1 = the round-3 schedule (panel solves on the update stream); 2 = bulk panel solves on the panel
+//      stream itself; 4 = no early part of the next group's first diagonal-block update
+//   9  round 4, posterior solves: block columns per step of the blocked triangular solves (default 2; 1 = round 3)
 #ifdef NNGP_TIMING_KNOBS
-extern std::atomic<int> g_knobs[8];
+extern std::atomic<int> g_knobs[16];
 #define NNGP_KNOB(i) (nngp::g_knobs[i].load(std::memory_order_relaxed))
 #else
 #define NNGP_KNOB(i) 0
@@ -153,8 +156,10 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
     int* counters = nullptr;   // 8 work counters of the persistent GEMM grid (one per XCD)
     bool l_ready = false;      // every block column of the current factor has been written
     int64_t split_panel = -1;  // block-column offset whose split copy was last written by the block-column ABI
-    char* ldiag = nullptr;     // 4 k_cap^2 bytes: split copy of the diagonal block being solved against, in the fragment order of k_trsm_panel_h3
-    float* dfrag = nullptr;    // k_cap x 128 floats: its inverted 128-blocks in the same fragment order
+    char* ldiag = nullptr;     // 2 x 4 k_cap^2 bytes: split copy of the diagonal block being solved against, in the fragment order of k_trsm_panel_h3
+    float* dfrag = nullptr;    // 2 x k_cap x 128 floats: its inverted 128-blocks in the same fragment order
+                               // (two of each, by block-column parity: the bulk rows of block column k are still being solved on the
+                               // solve stream of the grouped Cholesky while the panel stream prepares block column k + 1)
     char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)
     bool lt_ready = false;
     char* planes_b = nullptr;  // [mb_cap + 256][k_cap] x 4 bytes: the right-hand-side block of a blocked solve
@@ -165,10 +170,18 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
 struct LookAhead {  // streams and events of the look-ahead Cholesky (one per model)
     static constexpr int kMaxSteps = 64;
     hipStream_t panel = nullptr, update = nullptr;
+    hipStream_t bulk = nullptr;  // round 4: the panel solves of the rows beyond the next diagonal block (above the update stream's priority)
+    hipStream_t aux = nullptr;   // round 4: the early part of a group's product onto the next group's first diagonal block
     bool masked = false;  // streams own disjoint CU sets (hipExtStreamCreateWithCUMask)
     hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
     hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};
     hipEvent_t ev_chunk[kMaxSteps] = {}, ev_helper[kMaxSteps] = {};  // grouped form: a far chunk may start / its helper grid has finished
+    // round 4 (panel solves off the update stream): the update stream up to the far chunk of step k; up to the near update of block
+    // column k; the first rows / the other rows of block column k are solved; its diagonal block is split; the early part of the next
+    // group's first diagonal-block update is in place
+    hipEvent_t ev_far[kMaxSteps] = {}, ev_near[kMaxSteps] = {}, ev_tc[kMaxSteps] = {}, ev_tb[kMaxSteps] = {}, ev_split[kMaxSteps] = {},
+               ev_gp[kMaxSteps] = {};
+    hipEvent_t ev_bulk_done = nullptr;
     // live timing of the split-float16 trailing updates (nngp_model_update_timer): event pairs around each launch
     static constexpr int kMaxTimed = 320;  // split-float16 update launches of one factorisation (grouped form: ~3 per block column)
     bool time_updates = false;

@@ -22,7 +22,7 @@
 namespace nngp {
 
 #ifdef NNGP_TIMING_KNOBS
-std::atomic<int> g_knobs[8];  // timing experiments only (libnngp_hip_knobs.so: nngp_debug_set); zero-initialised
+std::atomic<int> g_knobs[16];  // timing experiments only (libnngp_hip_knobs.so: nngp_debug_set); zero-initialised
 #endif
 
 namespace {
@@ -614,18 +614,24 @@ int lookahead_create(LookAhead** out) {
             delete la;
             return -1;
         }
+        // the bulk panel solves: any priority above the update stream's, so that their workgroups take the compute units a trailing
+        // update launch gives back before the next launch's persistent grid settles on them (debug key 1 = 2: the middle level)
+        const int mid = (least + greatest) / 2;
+        if (hipStreamCreateWithPriority(&la->bulk, hipStreamNonBlocking, mid != least ? mid : greatest) != hipSuccess) la->bulk = nullptr;
+        if (hipStreamCreateWithPriority(&la->aux, hipStreamNonBlocking, greatest) != hipSuccess) la->aux = nullptr;
     }
-    hipEvent_t* all[3] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done};
+    hipEvent_t* all[4] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done, &la->ev_bulk_done};
     for (auto e : all)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
-    for (int i = 0; i < LookAhead::kMaxSteps; ++i)
-        if (hipEventCreateWithFlags(&la->ev_panel[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&la->ev_col[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&la->ev_chunk[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&la->ev_helper[i], hipEventDisableTiming) != hipSuccess) {
-            set_error("hipEventCreate failed");
-            return -1;
-        }
+    for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
+        hipEvent_t* per[10] = {&la->ev_panel[i], &la->ev_col[i], &la->ev_chunk[i], &la->ev_helper[i], &la->ev_far[i],
+                               &la->ev_near[i],  &la->ev_tc[i],  &la->ev_tb[i],    &la->ev_split[i],  &la->ev_gp[i]};
+        for (auto e : per)
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+                set_error("hipEventCreate failed");
+                return -1;
+            }
+    }
     *out = la;
     return 0;
 }
@@ -634,12 +640,18 @@ void lookahead_destroy(LookAhead* la) {
     if (!la) return;
     (void)hipStreamSynchronize(la->panel);
     (void)hipStreamSynchronize(la->update);
+    if (la->bulk) (void)hipStreamSynchronize(la->bulk);
     (void)hipStreamDestroy(la->panel);
     (void)hipStreamDestroy(la->update);
+    if (la->bulk) (void)hipStreamDestroy(la->bulk);
+    if (la->aux) { (void)hipStreamSynchronize(la->aux); (void)hipStreamDestroy(la->aux); }
     (void)hipEventDestroy(la->ev_in); (void)hipEventDestroy(la->ev_panel_done); (void)hipEventDestroy(la->ev_update_done);
+    if (la->ev_bulk_done) (void)hipEventDestroy(la->ev_bulk_done);
     for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
-        (void)hipEventDestroy(la->ev_panel[i]); (void)hipEventDestroy(la->ev_col[i]);
-        (void)hipEventDestroy(la->ev_chunk[i]); (void)hipEventDestroy(la->ev_helper[i]);
+        hipEvent_t per[10] = {la->ev_panel[i], la->ev_col[i], la->ev_chunk[i], la->ev_helper[i], la->ev_far[i],
+                              la->ev_near[i],  la->ev_tc[i],  la->ev_tb[i],    la->ev_split[i],  la->ev_gp[i]};
+        for (auto e : per)
+            if (e) (void)hipEventDestroy(e);
     }
     for (int i = 0; i < LookAhead::kMaxTimed; ++i) {
         if (la->tu0[i]) (void)hipEventDestroy(la->tu0[i]);
@@ -890,6 +902,282 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
     return rc;
 }
 
+// ---- grouped form, round 4: the panel solves leave the update stream ---------------------------------------------------------------
+// Round 3's timeline (profiles/r3_timeline_cfg3.csv) has 7.8 ms of panel solves, float32 diagonal-block updates and splits IN LINE
+// with the 28.4 ms of split-float16 trailing updates on the update stream, most of the chip idle meanwhile.  Here the update stream
+// carries the trailing updates only.  Per block column k:
+//   panel stream   P_k  factor the diagonal block               (needs the update stream up to the far chunk issued at step k - 1)
+//                  Tc_k solve the nb rows right below it        (needs the near update of block column k - 1)
+//                  G_k  their product onto diagonal block k + 1 (float32 MFMA, K = nb)           -> P_{k+1}
+//   bulk stream    Tb_k solve all other rows below              (same inputs as Tc_k; a priority above the update stream's: its
+//                       workgroups run on the compute units the trailing updates leave free and take over whatever a finishing
+//                       update launch gives back, before the next launch's persistent grid settles there)
+//   update stream  the far chunk of step k (previous group's panels, K = nb D), then N_k = block column k onto the rest of its
+//                       group (K = nb; needs Tc_k and Tb_k)
+// The next group's first diagonal block used to receive the whole finished group in one float32 GEMM (K = nb D) at the head of the
+// chain; now the D - 1 earlier panels go there as soon as THEY are solved (bulk stream, behind Tb of the group's last-but-one
+// column) and only the last panel's K = nb product is left in the chain.  The split copy of a diagonal block and its inverted
+// 128-blocks (operands of the fused solves) alternate between two buffers: Tb_k may still be reading one while the panel stream
+// prepares block column k + 1.
+static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, LookAhead* la,
+                                      SplitWork* sw, hipStream_t user, int64_t nb, int D) {
+    la->tu_count = 0;
+    hipStream_t SP = la->panel, SU = la->update, SB = (NNGP_KNOB(8) & 2) ? la->panel : la->bulk;
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_in, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(SU, la->ev_in, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(SB, la->ev_in, 0));
+    const int nblk = (int)((n + nb - 1) / nb);
+    const int64_t ldp = 4 * sw->k_cap;
+    const float ascale = -1.0f / (sw->scale * sw->scale);
+    const int reserve = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
+    const int64_t lead0 = 64;  // columns of block column 0 that stay on the float32 MFMA (see potrf_lookahead_f32)
+    const bool use_helper = !(NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) && reserve >= 8 && reserve % 8 == 0;
+    const bool early_gp = !(NNGP_KNOB(8) & 4);
+    auto plane_rows = [&](int col, int64_t row) { return sw->planes + (int64_t)col * sw->col_stride + row * ldp; };
+    auto width = [&](int64_t col0) { return (n - col0 < nb) ? n - col0 : nb; };
+    FarWork far;
+    // a far chunk's helper grid (see potrf_lookahead_grouped) is enqueued on the panel stream BEHIND the step's chain work
+    struct PendingHelper {
+        bool on = false;
+        H3RegionSpec reg[4];
+        int nreg = 0, kl = 0, np = 0, step = 0;
+        int64_t lead = 0;
+    } ph;
+
+    auto timed_begin = [&]() -> int {
+        const bool timed = la->time_updates && la->tu_count < LookAhead::kMaxTimed;
+        if (timed) {
+            const int t = la->tu_count;
+            if (la->tu0[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu0[t]));
+            if (la->tu1[t] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&la->tu1[t]));
+            NNGP_HIP_CHECK(hipEventRecord(la->tu0[t], SU));
+        }
+        return timed ? 1 : 0;
+    };
+    auto timed_end = [&](const H3RegionSpec* reg, int nreg, double kk) -> int {
+        const int t = la->tu_count++;
+        NNGP_HIP_CHECK(hipEventRecord(la->tu1[t], SU));
+        double entries = 0.0, rows_cols = 0.0;
+        for (int r = 0; r < nreg; ++r) {
+            entries += trap_entries(reg[r].m, reg[r].n, reg[r].shift);
+            rows_cols += (double)reg[r].m + (double)reg[r].n;
+        }
+        la->tu_flops[t] = 2.0 * entries * kk;
+        la->tu_bytes[t] = 8.0 * entries + 4.0 * rows_cols * kk;
+        return 0;
+    };
+    // one split-float16 launch of the pending group's far update over `reg` (+ the float32 pass of the group's lead columns)
+    auto far_launch = [&](const H3RegionSpec* reg, int nreg, int step, bool allow_helper) -> int {
+        if (nreg == 0) return 0;
+        const int kl = far.g0 + far.np - 1;  // latest panel
+        const int64_t lead = far.g0 == 0 ? lead0 : 0;
+        double tiles = 0.0;
+        for (int r = 0; r < nreg; ++r) tiles += trap_entries(reg[r].m, reg[r].n, reg[r].shift) / 65536.0;
+        // (a pass with lead columns is followed by float32 launches over the same regions: no helper there)
+        const bool helper = allow_helper && use_helper && lead == 0 && step >= 0 && tiles * (double)far.np >= 4.0 * 3.0 * 224.0;
+        const int timed = timed_begin();
+        if (timed < 0) return timed;
+        if (helper) NNGP_HIP_CHECK(hipEventRecord(la->ev_chunk[step], SU));
+        NNGP_TRY(launch_gemm_nt_h3r(a, ld, plane_rows(kl, 0), plane_rows(kl, 0), ldp, sw->col_stride, far.np, lead, reg, nreg, nb, ascale, 1.0f,
+                                    true, sw->counters, reserve, SU, nullptr, helper ? 1 : 0));
+        if (timed) NNGP_TRY(timed_end(reg, nreg, (double)far.np * (double)nb - (double)lead));
+        if (helper) {
+            ph.on = true;
+            ph.nreg = nreg;
+            for (int r = 0; r < nreg; ++r) ph.reg[r] = reg[r];
+            ph.kl = kl; ph.np = far.np; ph.step = step; ph.lead = lead;
+        }
+        if (lead > 0) {  // columns [0, lead) of block column 0
+            for (int r = 0; r < nreg; ++r) {
+                float* cr = a + reg[r].row0 * ld + reg[r].col0;
+                const float* pa = a + reg[r].row0 * ld;
+                const float* pb = a + reg[r].col0 * ld;
+                if (reg[r].shift == 0) {
+                    NNGP_TRY(f32_update_trap(cr, ld, pa, pb, reg[r].m, reg[r].n, lead, SU));
+                } else {  // rows start `shift` below the columns: every entry of the columns is in
+                    NNGP_TRY(launch_gemm_nt_f32(cr, ld, pa, ld, pb, ld, reg[r].m, reg[r].n, lead, -1.0f, 1.0f, false, SU));
+                }
+            }
+        }
+        return 0;
+    };
+    // the pieces of the pending far update that belong to step `step` (block column gend + i of the next group is being factored)
+    auto far_step = [&](int step, bool* colrows_event) -> int {
+        if (!far.active || far.next >= far.nchunks) return 0;
+        const int i = far.next++;
+        const int64_t r0 = far.r0;
+        H3RegionSpec reg[4];
+        int nreg = 0;
+        auto add = [&](int64_t row0, int64_t col0, int64_t w, int64_t shift) {
+            if (n - row0 > 0 && w > 0) reg[nreg++] = H3RegionSpec{row0, col0, n - row0, w, shift};
+        };
+        if (i == 0) {  // rows of the next group's first column below its diagonal block: its panel solve waits for exactly these
+            const int64_t w0 = width(r0);
+            add(r0 + w0, r0, w0, w0);
+            if (nreg > 0 && step >= 0) {
+                NNGP_TRY(far_launch(reg, nreg, step, false));
+                NNGP_HIP_CHECK(hipEventRecord(la->ev_col[step], SU));
+                *colrows_event = true;
+                nreg = 0;
+            }
+        }
+        const int64_t c1 = r0 + (int64_t)(i + 1) * nb;  // column gend + i + 1, if it belongs to the next group
+        if (c1 < n && i + 1 < D) add(c1, c1, width(c1), 0);
+        // shares are dealt from the LAST chunk backwards: the early chunks already carry the next group's own columns
+        const int si = far.nchunks - 1 - i;
+        if (far.share_lo[si + 1] > far.share_lo[si]) add(far.share_lo[si], far.share_lo[si], far.share_lo[si + 1] - far.share_lo[si], 0);
+        if (far.next >= far.nchunks) far.active = false;
+        return far_launch(reg, nreg, step, true);
+    };
+
+    int rc = 0;
+    for (int k = 0; k < nblk && rc == 0; ++k) {
+        const int64_t o = (int64_t)k * nb;
+        const int64_t nbk = width(o);
+        const int64_t m = n - o - nbk;  // rows below this block column
+        float* akk = a + o * ld + o;
+        float* dk = dinv + (o / TB) * TB * TB;
+        const int g0 = (k / D) * D;
+        const int gend = (g0 + D < nblk) ? g0 + D : nblk;
+        // ---- panel stream: P_k ----
+        if (k > 0) NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_far[k - 1], 0));
+        rc = potrf_rec(akk, nbk, ld, dk, clamped, pivot_floor, SP);
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_panel[k], SP));
+        if (rc != 0) break;
+        // ---- update stream: this step's share of the previous group's far update ----
+        bool colrows = false;
+        ph.on = false;
+        rc = far_step(k, &colrows);
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_far[k], SU));
+        if (rc != 0 || m == 0) break;
+        // ---- the panel solves: Tc_k on the panel stream, Tb_k on the bulk stream ----
+        const int64_t nb2 = width(o + nbk);
+        float* below = akk + nbk * ld;           // panel rows below the diagonal block: [m, nbk]
+        float* c = below + nbk;                  // trailing matrix: [m, m]
+        char* pk_rows = plane_rows(k, o + nbk);
+        hipEvent_t ev_rows = nullptr;            // block column k below its diagonal block has received everything
+        if (k > g0) ev_rows = la->ev_near[k - 1];
+        else if (colrows) ev_rows = la->ev_col[k];
+        if (ev_rows != nullptr) NNGP_HIP_CHECK(hipStreamWaitEvent(SP, ev_rows, 0));
+        const bool solve_h3 = k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr;
+        char* ldiag = sw->ldiag + (int64_t)(k & 1) * 4 * sw->k_cap * sw->k_cap;
+        float* dfrag = sw->dfrag + (int64_t)(k & 1) * sw->k_cap * 128;
+        if (solve_h3) {
+            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, ldiag, dk, dfrag, SP);
+            if (rc == 0) rc = launch_trsm_panel_h3(below, ld, nb2, ldiag, dfrag, nbk, pk_rows, ldp, sw->scale, SP);
+        } else {
+            rc = launch_trsm_panel_f32(below, ld, nb2, akk, ld, dk, nbk, pk_rows, ldp, sw->scale, SP);
+        }
+        if (rc != 0) break;
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_tc[k], SP));  // (also: the diagonal block is factored and split)
+        if (m > nb2) {
+            NNGP_HIP_CHECK(hipStreamWaitEvent(SB, la->ev_tc[k], 0));
+            if (ev_rows != nullptr) NNGP_HIP_CHECK(hipStreamWaitEvent(SB, ev_rows, 0));
+            if (solve_h3)
+                rc = launch_trsm_panel_h3(below + nb2 * ld, ld, m - nb2, ldiag, dfrag, nbk, pk_rows + nb2 * ldp, ldp, sw->scale, SB);
+            else
+                rc = launch_trsm_panel_f32(below + nb2 * ld, ld, m - nb2, akk, ld, dk, nbk, pk_rows + nb2 * ldp, ldp, sw->scale, SB);
+            if (rc != 0) break;
+        }
+        NNGP_HIP_CHECK(hipEventRecord(la->ev_tb[k], SB));
+        // the far chunk's helper grid joins from the panel stream once the chain work it does not depend on is out
+        if (ph.on) {
+            NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_chunk[ph.step], 0));
+            rc = launch_gemm_nt_h3r(a, ld, plane_rows(ph.kl, 0), plane_rows(ph.kl, 0), ldp, sw->col_stride, ph.np, ph.lead, ph.reg, ph.nreg, nb,
+                                    ascale, 1.0f, true, sw->counters, reserve, SP, nullptr, 2);
+            if (rc != 0) break;
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_helper[ph.step], SP));
+            NNGP_HIP_CHECK(hipStreamWaitEvent(SU, la->ev_helper[ph.step], 0));
+            ph.on = false;
+        }
+        // ---- G_k, the product of the rows just solved onto the next diagonal block.  This step's far chunk carries that block's
+        // share of the previous group (same C tiles): the product waits for it, as P_{k+1} has to anyway. ----
+        NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_far[k], 0));
+        if (k + 1 < gend) {
+            rc = launch_gemm_nt_f32(c, ld, below, ld, below, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, SP);
+        } else {
+            // The next group's first diagonal block receives the whole finished group.  Its D - 1 earlier panels are solved once the
+            // bulk stream has passed Tb_{k-1}, and the previous group's last far chunk (this step's: it covers that block too) has to
+            // be through: behind both, on a stream of its own, the K = nb (D - 1) product runs beside P_k when the chain is what
+            // bounds the factorisation (the late block columns); only the last panel's K = nb product is left in the chain.
+            const int np = k + 1 - g0;
+            const float* rows = a + (o + nbk) * ld + (int64_t)g0 * nb;  // rows of the next diagonal block, columns of the group
+            if (early_gp && np >= 2 && la->aux != nullptr) {
+                NNGP_HIP_CHECK(hipStreamWaitEvent(la->aux, la->ev_far[k], 0));
+                NNGP_HIP_CHECK(hipStreamWaitEvent(la->aux, la->ev_tb[k - 1], 0));
+                rc = launch_gemm_nt_f32(c, ld, rows, ld, rows, ld, nb2, nb2, (int64_t)(np - 1) * nb, -1.0f, 1.0f, true, la->aux);
+                if (rc != 0) break;
+                NNGP_HIP_CHECK(hipEventRecord(la->ev_gp[k], la->aux));
+                NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_gp[k], 0));
+                rc = launch_gemm_nt_f32(c, ld, below, ld, below, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, SP);
+            } else {  // all panels of the group at once (the earlier panels' rows were solved on the bulk stream)
+                if (np >= 2) NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_tb[k - 1], 0));
+                rc = launch_gemm_nt_f32(c, ld, rows, ld, rows, ld, nb2, nb2, (int64_t)np * nb, -1.0f, 1.0f, true, SP);
+            }
+        }
+        if (rc != 0) break;
+        // ---- update stream: block column k is solved ----
+        NNGP_HIP_CHECK(hipStreamWaitEvent(SU, la->ev_tc[k], 0));
+        NNGP_HIP_CHECK(hipStreamWaitEvent(SU, la->ev_tb[k], 0));
+        if (k + 1 < gend) {
+            // inside the group: block column k goes to the group's remaining columns only (K = nbk)
+            int64_t wn = (int64_t)(gend - 1 - k) * nb;  // columns of the group after block column k
+            if (wn > m) wn = m;
+            const int64_t lead = (k == 0) ? lead0 : 0;
+            if (m > nb2) {
+                rc = h3_update_timed(la, c + nb2 * ld, ld, pk_rows + nb2 * ldp + lead * 4, pk_rows + lead * 4, ldp, 0, 1, 0, m - nb2, wn, nbk - lead,
+                                     ascale, true, nb2, sw, reserve, trap_entries(m - nb2, wn, nb2));
+                if (rc == 0 && lead > 0) {
+                    rc = launch_gemm_nt_f32(c + nb2 * ld, ld, below + nb2 * ld, ld, below, ld, m - nb2, nb2, lead, -1.0f, 1.0f, false, SU);
+                    if (rc == 0 && wn > nb2)
+                        rc = f32_update_trap(c + nb2 * ld + nb2, ld, below + nb2 * ld, below + nb2 * ld, m - nb2, wn - nb2, lead, SU);
+                }
+            }
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_near[k], SU));
+        } else {
+            // the group is complete: set up its far update (issued in pieces at the next steps)
+            const int np = k + 1 - g0;
+            far = FarWork();
+            far.active = true;
+            far.g0 = g0;
+            far.np = np;
+            far.r0 = o + nbk;
+            const int dn = (nblk - (k + 1) < D) ? nblk - (k + 1) : D;  // block columns of the next group
+            far.nchunks = dn;
+            // shares of the columns beyond the next group: equal trapezoid areas, whole block columns; few, large launches
+            const int64_t f0 = far.r0 + (int64_t)dn * nb;
+            for (int i = 0; i <= dn; ++i) far.share_lo[i] = f0 < n ? f0 : n;
+            if (f0 < n) {
+                const int64_t mf = n - f0;
+                const double total = 0.5 * (double)mf * (double)mf;
+                const double tiles = total / (256.0 * 256.0);
+                int ns = (int)(tiles / 700.0);  // >= ~3 tiles per compute unit and launch
+                if (ns < 1) ns = 1;
+                if (ns > dn) ns = dn;
+                double acc_area = 0.0;
+                int sidx = 1;
+                for (int64_t col = f0; col < n; col += nb) {
+                    const int64_t w = width(col);
+                    acc_area += (double)(n - col) * (double)w - 0.5 * (double)w * (double)w;
+                    if (sidx < ns && acc_area >= total * sidx / ns) far.share_lo[sidx++] = col + w;
+                }
+                for (int i = sidx; i <= dn; ++i) far.share_lo[i] = n;
+            }
+        }
+    }
+    bool dummy = false;
+    while (rc == 0 && far.active) rc = far_step(-1, &dummy);  // (nothing is left when the loop ran to the last block column)
+    if (rc == 0) sw->l_ready = true;
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, SP));
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, SU));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_panel_done, 0));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_update_done, 0));
+    NNGP_HIP_CHECK(hipEventRecord(la->ev_bulk_done, SB));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_bulk_done, 0));
+    return rc;  // (the aux stream's last product was waited for by the panel stream)
+}
+
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
                         LookAhead* la, SplitWork* sw, hipStream_t user) {
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
@@ -910,8 +1198,11 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         return potrf_f32(a, n, ld, dinv, clamped, pivot_floor, user);
     // grouped form: deep-K far updates (debug key 2 = 10 + D overrides the group size; D = 1: the round-2 form below)
     const int group = (NNGP_KNOB(2) >= 11 && NNGP_KNOB(2) <= 26) ? NNGP_KNOB(2) - 10 : (NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) ? NNGP_KNOB(2) - 30 : kLookAheadGroup;
-    if (h3 && group > 1 && nb == 1024 && (NNGP_KNOB(2) == 0 || NNGP_KNOB(2) >= 11) && NNGP_KNOB(3) == 0 && ld % 4 == 0)
+    if (h3 && group > 1 && nb == 1024 && (NNGP_KNOB(2) == 0 || NNGP_KNOB(2) >= 11) && NNGP_KNOB(3) == 0 && ld % 4 == 0) {
+        if (la->bulk != nullptr && !(NNGP_KNOB(8) & 1))
+            return potrf_lookahead_grouped_v4(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
         return potrf_lookahead_grouped(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
+    }
     la->tu_count = 0;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(la->panel, la->ev_in, 0));

@@ -345,6 +345,38 @@ def test_grouped_cholesky_matches_the_one_column_form(n):
     assert (l1 - l4).abs().max().item() <= 2e-3 * l1.abs().max().item()
 
 
+@pytest.mark.parametrize("n", [9300, 13440])
+def test_cholesky_schedule_with_the_panel_solves_off_the_update_stream(n):
+    """Round 4's schedule of the grouped Cholesky (panel solves on the panel / bulk streams, trailing updates alone on the update
+    stream, the far chunk of a group's first step in two launches) against round 3's (debug key 8 = 1: everything but the
+    diagonal-block factorisations in line on the update stream).  With the early part of the next group's first diagonal-block
+    update switched off (key 8 = 4) every tile sees the same arithmetic in the same order: the factors must agree BIT FOR BIT --
+    any read-modify-write race between the four streams would show here.  The default (early part on) differs by float32
+    rounding in those diagonal blocks only; alpha, the float64 CG answer, agrees to 1e-9 and the CG takes the same iterations."""
+    from nngp_src_amd import _lib
+    x, y = synth.synthetic_queries(n, 48, seed=41)
+    lib = _lib.load(knobs=True)
+    res = {}
+    for key8 in (1, 4, 4, 0, 0):
+        lib.nngp_debug_set(8, key8)
+        try:
+            mdl = GPModel(n, 48, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+            a32, _ = mdl.factor_buffers()
+            res.setdefault(key8, []).append((mdl.info(), mdl.alpha().cpu().numpy().copy(), torch.tril(a32[:n, :n]).clone()))
+            mdl.close()
+        finally:
+            lib.nngp_debug_set(8, 0)
+    (i3, a3, l3) = res[1][0]
+    for (i4, a4, l4) in res[4]:
+        assert i4["clamped_pivots"] == 0
+        assert torch.equal(l3, l4) and np.array_equal(a3, a4)
+    (i0, a0, l0), (_, a0b, l0b) = res[0]
+    assert torch.equal(l0, l0b) and np.array_equal(a0, a0b)
+    assert i0["clamped_pivots"] == 0 and i0["rel_residual"] < 1e-9 and abs(i0["refine_iters"] - i3["refine_iters"]) <= 1
+    assert np.linalg.norm(a0 - a3) <= 1e-9 * np.linalg.norm(a3)
+    assert (l0 - l3).abs().max().item() <= 2e-3 * l3.abs().max().item()
+
+
 @pytest.mark.parametrize("rows", [128, 512, 24576 + 128])  # 64x128 and 128x128 workgroup tiles
 def test_gemm_in_place_inverse_block(rows):
     torch.manual_seed(2)
