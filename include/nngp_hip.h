@@ -302,6 +302,15 @@ int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, doub
  * travel to the host.  count <= m. */
 int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased,
                      uint64_t seed, int64_t* indices, void* stream);
+/* The float32 factor of a fitted model applied to a block of right-hand-side ROWS, as the posterior does it (reference:
+ * the cho_solve inside predict_fn, train.py:157-158 through neural-tangents' nt.predict): b [rows, n] float32, row stride n
+ * (n = the model's training rows; rows a multiple of 128 is not required), overwritten with
+ *   mode 0:  b L^-T            (the forward half: what the variance's L^-1 k needs)
+ *   mode 1:  b (L L^T)^-1      (both halves: the preconditioner M^-1 of the refinement sweeps)
+ * through the blocked solves the model would take for a block of that size (inverted diagonal blocks, the large updates on the
+ * float16 pipe from 256 rows and N = 8192 on).  L is the factor of float32(K) + reg I: compare against a triangular solve with
+ * the factor itself (nngp_model_factor_buffers), not against the float64 kernel. */
+int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode, void* stream);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,
                       int64_t n, void* stream);

@@ -224,7 +224,9 @@ int ensure_predict_capacity(nngp_model* m, int64_t mt, bool need_ktd) {
             dev_free(m->split.planes_b); dev_free(m->split.row_inv);
             m->split.planes_b = nullptr; m->split.row_inv = nullptr;
             m->split.mb_cap = round_up(cap, TB);
-            NNGP_TRY(dev_alloc(&m->split.planes_b, (m->split.mb_cap + 256) * m->split.k_cap * 4));
+            // one panel per 1024 columns of a solve step, col_stride bytes apart (see SplitWork)
+            m->split.b_panels = (int)((triinv_block(m->np_cap) + m->split.k_cap - 1) / m->split.k_cap);
+            NNGP_TRY(dev_alloc(&m->split.planes_b, (int64_t)(m->split.b_panels - 1) * m->split.col_stride + (m->split.mb_cap + 256) * m->split.k_cap * 4));
             NNGP_TRY(dev_alloc(&m->split.row_inv, m->split.mb_cap));
         }
         m->m_cap = cap;
@@ -514,8 +516,8 @@ int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z
 // diag-variance call at level 2, float16 / float32 solves -- N = 10800: M = 128: 6.5 / 5.6, 512: 9.1 / 8.8, 1024: 11.5 / 12.9;
 // N = 32768: M = 128: 21.8 / 20.1, 256: 29.3 / 30.6, 512: 40.6 / 51.5)
 bool use_split_solves(const nngp_model* m, int64_t mp) {
-    return m->split.l_ready && m->split.planes_b != nullptr && mp <= m->split.mb_cap && m->tri.bs == m->split.k_cap &&
-           NNGP_KNOB(7) == 0 && mp >= 256 && mp * m->np >= 7000000;
+    return m->split.l_ready && m->split.planes_b != nullptr && mp <= m->split.mb_cap && m->tri.bs % m->split.k_cap == 0 &&
+           m->tri.bs / m->split.k_cap <= m->split.b_panels && m->tri.bs <= 2048 && NNGP_KNOB(7) == 0 && mp >= 256 && mp * m->np >= 7000000;
 }
 
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
@@ -886,7 +888,7 @@ int nngp_model_factor_end(nngp_model* m, void* stream) {
     NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
     // the float16-split copy of L by block column, if the factorisation did not leave one behind (recursion at
     // 4096 <= N, block-column ABI of the distributed factorisation): the posterior's solves use it
-    if (!m->split.l_ready && m->split.planes != nullptr && m->np >= 4 * m->split.k_cap && m->tri.bs == m->split.k_cap &&
+    if (!m->split.l_ready && m->split.planes != nullptr && m->np >= 4 * m->split.k_cap && m->tri.bs % m->split.k_cap == 0 &&
         m->split.rows_cap >= m->np + 256) {
         const int64_t bs = m->split.k_cap, ldp = 4 * bs;
         for (int64_t j = 0, o = 0; o + bs < m->np; ++j, o += bs)
@@ -1629,6 +1631,20 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     }
     NNGP_HIP_CHECK(hipEventRecord(m->ev_predict, s));
     m->have_predict_event = true;
+    return 0;
+}
+
+int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->factored, "apply_factor: fit the model first");
+    NNGP_REQUIRE(b != nullptr && rows > 0 && (mode == 0 || mode == 1), "apply_factor: bad arguments");
+    NNGP_TRY(ensure_predict_capacity(m, rows, false));
+    const int64_t mp = round_up(rows, TB), np = m->np, n = m->n;
+    NNGP_HIP_CHECK(hipMemsetAsync(m->b32, 0, sizeof(float) * mp * np, s));
+    NNGP_HIP_CHECK(hipMemcpy2DAsync(m->b32, sizeof(float) * np, b, sizeof(float) * n, sizeof(float) * n, rows, hipMemcpyDeviceToDevice, s));
+    if (mode == 0) NNGP_TRY(apply_forward_f32(m, mp, s));
+    else NNGP_TRY(apply_inverse_f32(m, mp, s));
+    NNGP_HIP_CHECK(hipMemcpy2DAsync(b, sizeof(float) * n, m->b32, sizeof(float) * np, sizeof(float) * n, rows, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 

@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
 //   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
 //   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
 //   8  round 4, grouped Cholesky: 1 = the round-3 schedule (panel solves on the update stream); 2 = bulk panel solves on the panel
-//      stream itself; 4 = no early part of the next group's first diagonal-block update
+//      stream itself; 4 = no early part of the next group's first diagonal-block update; 8 = helper grids on the panel stream
 //   9  round 4, posterior solves: block columns per step of the blocked triangular solves (default 2; 1 = round 3)
 #ifdef NNGP_TIMING_KNOBS
 extern std::atomic<int> g_knobs[16];
@@ -114,7 +114,7 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
 int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,
                       hipStream_t s);
 int launch_split_rows_rowscale(const float* src, int64_t ld_src, int64_t rows, int64_t k, float* copy_dst, int64_t ld_copy,
-                               char* out, int64_t out_ld, float* row_inv, hipStream_t s);
+                               char* out, int64_t out_ld, float* row_inv, hipStream_t s, int64_t pan_stride = 0);  // k <= 2048: panels of 1024 columns
 int launch_split_lower_t(const float* l, int64_t ld, int64_t n, int64_t bs, float scale, char* out, int64_t col_stride,
                          hipStream_t s);
 int launch_gemm_nt_h3(float* c, int64_t ldc, const char* a, const char* b, int64_t ldp, int64_t m, int64_t n, int64_t k,
@@ -162,7 +162,10 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
                                // solve stream of the grouped Cholesky while the panel stream prepares block column k + 1)
     char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)
     bool lt_ready = false;
-    char* planes_b = nullptr;  // [mb_cap + 256][k_cap] x 4 bytes: the right-hand-side block of a blocked solve
+    char* planes_b = nullptr;  // [mb_cap + 256][k_cap] x 4 bytes: the right-hand-side block of a blocked solve; round 4: one such panel per
+                               // 1024 columns of a solve step, col_stride bytes apart (the split-float16 kernel walks the panels of both
+                               // operands with ONE stride, and the factor's is col_stride)
+    int b_panels = 1;          // panels planes_b has room for
     float* row_inv = nullptr;  // [mb_cap] per-row 1/scale of planes_b
     int64_t mb_cap = 0;
 };

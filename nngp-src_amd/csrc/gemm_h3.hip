@@ -65,18 +65,21 @@ __global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ p,
 // One row per wave: split a float32 row with its OWN power-of-two scale (largest entry -> 2^14), write 1/scale to
 // row_inv (the GEMM epilogue multiplies it back) and, optionally, copy the float32 row to copy_dst.  Used for the
 // right-hand-side blocks of the blocked triangular solves, whose magnitudes change from sweep to sweep.
+template <int NV>
 __global__ __launch_bounds__(256) void k_split_rows_rowscale(const float* __restrict__ src, int64_t ld_src, int64_t rows,
                                                              int k, float* __restrict__ copy_dst, int64_t ld_copy,
-                                                             char* __restrict__ out, int64_t out_ld,
+                                                             char* __restrict__ out, int64_t out_ld, int64_t pan_stride,
                                                              float* __restrict__ row_inv) {
+    // NV float4 per lane: k <= 256 NV.  Columns [1024 p, 1024 p + 1024) of a row go to panel p, pan_stride bytes after panel p - 1
+    // (round 4: a step of the blocked solves covers several 1024-column panels; ONE scale per row over all of them)
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const float* p = src + r * ld_src;
-    f32x4 v[4];
+    f32x4 v[NV];
     float mx = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int k0 = 4 * (lane + 64 * i);
         v[i] = (k0 < k) ? *reinterpret_cast<const f32x4*>(p + k0) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void k_split_rows_rowscale(const float* __rest
     if (lane == 0) row_inv[r] = 1.0f / sc;
     char* o = out + r * out_ld;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int k0 = 4 * (lane + 64 * i);
         if (k0 >= k) continue;
         if (copy_dst != nullptr) *reinterpret_cast<f32x4*>(copy_dst + r * ld_copy + k0) = v[i];
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(256) void k_split_rows_rowscale(const float* __rest
             hi[e] = h;
             lo[e] = (_Float16)(a - (float)h);
         }
-        char* dst = o + (int64_t)(k0 >> 5) * 128 + (k0 & 31) * 2;
+        const int kp = k0 & 1023;
+        char* dst = o + (int64_t)(k0 >> 10) * pan_stride + (int64_t)(kp >> 5) * 128 + (kp & 31) * 2;
         *reinterpret_cast<h4*>(dst) = hi;
         *reinterpret_cast<h4*>(dst + 64) = lo;
     }
@@ -832,14 +836,19 @@ int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float
 }
 
 int launch_split_rows_rowscale(const float* src, int64_t ld_src, int64_t rows, int64_t k, float* copy_dst, int64_t ld_copy,
-                               char* out, int64_t out_ld, float* row_inv, hipStream_t s) {
+                               char* out, int64_t out_ld, float* row_inv, hipStream_t s, int64_t pan_stride) {
     if (rows <= 0) return 0;
-    NNGP_REQUIRE(k > 0 && k <= 1024 && k % 32 == 0 && ld_src % 4 == 0 && ((uintptr_t)src & 15) == 0 && out_ld >= 4 * k &&
-                     out_ld % 16 == 0 && ((uintptr_t)out & 15) == 0 && row_inv != nullptr &&
+    const int64_t kp = k < 1024 ? k : 1024;  // columns per panel
+    NNGP_REQUIRE(k > 0 && k <= 2048 && k % 32 == 0 && ld_src % 4 == 0 && ((uintptr_t)src & 15) == 0 && out_ld >= 4 * kp &&
+                     out_ld % 16 == 0 && ((uintptr_t)out & 15) == 0 && row_inv != nullptr && (k <= 1024 || (pan_stride > 0 && pan_stride % 16 == 0)) &&
                      (copy_dst == nullptr || (ld_copy % 4 == 0 && ((uintptr_t)copy_dst & 15) == 0)),
-                 "split_rows_rowscale: k must be a multiple of 32, at most 1024, operands 16-byte aligned");
-    hipLaunchKernelGGL(k_split_rows_rowscale, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, src, ld_src, rows, (int)k,
-                       copy_dst, ld_copy, out, out_ld, row_inv);
+                 "split_rows_rowscale: k must be a multiple of 32, at most 2048, operands 16-byte aligned");
+    if (k <= 1024)
+        hipLaunchKernelGGL((k_split_rows_rowscale<4>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, src, ld_src, rows, (int)k,
+                           copy_dst, ld_copy, out, out_ld, pan_stride, row_inv);
+    else
+        hipLaunchKernelGGL((k_split_rows_rowscale<8>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, src, ld_src, rows, (int)k,
+                           copy_dst, ld_copy, out, out_ld, pan_stride, row_inv);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1081,13 +1081,16 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
             if (rc != 0) break;
         }
         NNGP_HIP_CHECK(hipEventRecord(la->ev_tb[k], SB));
-        // the far chunk's helper grid joins from the panel stream once the chain work it does not depend on is out
+        // The far chunk's helper grid: the `reserve` compute units the chunk's own grid leaves free carry the diagonal-block chain (a
+        // workgroup at a time) and the bulk solve; once Tb_k is through, that many workgroups join the chunk from the bulk stream
+        // (debug key 8 = 8: from the panel stream, behind Tc_k, as in round 3 -- there they compete with Tb_k for the same units).
         if (ph.on) {
-            NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_chunk[ph.step], 0));
+            hipStream_t SH = (NNGP_KNOB(8) & 8) ? SP : SB;
+            NNGP_HIP_CHECK(hipStreamWaitEvent(SH, la->ev_chunk[ph.step], 0));
             rc = launch_gemm_nt_h3r(a, ld, plane_rows(ph.kl, 0), plane_rows(ph.kl, 0), ldp, sw->col_stride, ph.np, ph.lead, ph.reg, ph.nreg, nb,
-                                    ascale, 1.0f, true, sw->counters, reserve, SP, nullptr, 2);
+                                    ascale, 1.0f, true, sw->counters, reserve, SH, nullptr, 2);
             if (rc != 0) break;
-            NNGP_HIP_CHECK(hipEventRecord(la->ev_helper[ph.step], SP));
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_helper[ph.step], SH));
             NNGP_HIP_CHECK(hipStreamWaitEvent(SU, la->ev_helper[ph.step], 0));
             ph.on = false;
         }

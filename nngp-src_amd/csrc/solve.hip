@@ -272,8 +272,10 @@ int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_
     return 0;
 }
 
+// Round 4: 2048-wide inverted blocks from np = 8192 on (the sizes whose posterior solves run on the float16 pipe): the blocked solves take
+// half as many steps, each with K = 2048 per pass over the right-hand sides, and the CG's blocked TRSVs half as many launches.
 int64_t triinv_block(int64_t np) {
-    const int64_t bs = NNGP_KNOB(6) >= 128 ? (int64_t)NNGP_KNOB(6) : 1024;  // debug key 6: block size experiment
+    int64_t bs = NNGP_KNOB(6) >= 128 ? (int64_t)NNGP_KNOB(6) : (np >= 8192 && NNGP_KNOB(9) != 1) ? 2048 : 1024;  // debug key 6: block size experiment; 9 = 1: round 3
     return np < bs ? np : bs;
 }
 
@@ -333,25 +335,49 @@ int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64
     return 0;
 }
 
-// Blocked solves with the large trailing products on the float16 pipe.  Per block column J: the diagonal solve stays a
-// float32 GEMM with the inverted block (into `tmp`); k_split_rows_rowscale copies it back and writes its split copy
-// (one power-of-two scale per right-hand-side row); the trailing update is one split-float16 launch against the
-// split copy of L (forward) or L^T (backward).  Steps whose update has too few 256 x 256 tiles to fill the GPU stay
-// on the float32 kernel (64 x 64 tiles).
+// Blocked solves with the large trailing products on the float16 pipe.  Per block column J (ti.bs columns: round 4 takes
+// TWO 1024-column panels per step where the inverted diagonal blocks are 2048 wide -- half the steps of the latency chain
+// {diagonal GEMM, split, update}, and every update tile accumulates K = 2048 per pass over C): the diagonal solve stays a
+// float32 GEMM with the inverted block (into `tmp`); k_split_rows_rowscale copies it back and writes its split copy (one
+// power-of-two scale per right-hand-side row, one 1024-column panel after the other, col_stride bytes apart like the
+// factor's own panels); the trailing update is one multi-panel split-float16 launch against the split copy of L (forward)
+// or L^T (backward).  Steps whose update has too few 256 x 256 tiles to fill the GPU stay on the float32 kernel
+// (64 x 64 tiles).
 static bool h3_worth(int64_t m, int64_t cols) { return ((m + 255) / 256) * ((cols + 255) / 256) >= 96; }
+
+// C [m, n] -= X_J W^T for the step's block X_J (sz columns, split in sw.planes_b by panels of kc columns) and the matching
+// panels of the factor's split copy: wrows = split rows of W's first row in the step's FIRST (lowest-k) panel.
+static int h3_step_update(float* c, int64_t ldc, int64_t m, int64_t n, int64_t sz, const char* wrows, const SplitWork& sw, hipStream_t s) {
+    const int64_t kc = sw.k_cap, ldp = 4 * kc;
+    const int np = (int)((sz + kc - 1) / kc);
+    const float alpha = -1.0f / sw.scale;
+    if (sz % kc == 0)  // equal panels: one pass over C, the latest panel first
+        return launch_gemm_nt_h3x(c, ldc, sw.planes_b + (int64_t)(np - 1) * sw.col_stride, wrows + (int64_t)(np - 1) * sw.col_stride, ldp,
+                                  sw.col_stride, np, 0, m, n, kc, alpha, 1.0f, false, 0, sw.counters, 0, s, sw.row_inv);
+    for (int p = np - 1; p >= 0; --p) {  // a short last panel (tail of the matrix): one launch per panel
+        const int64_t kp = (p == np - 1) ? sz - (int64_t)p * kc : kc;
+        NNGP_TRY(launch_gemm_nt_h3(c, ldc, sw.planes_b + (int64_t)p * sw.col_stride, wrows + (int64_t)p * sw.col_stride, ldp, m, n, kp, alpha,
+                                   1.0f, false, 0, sw.counters, 0, s, sw.row_inv));
+    }
+    return 0;
+}
+
+static bool h3_step_ok(const SplitWork& sw, int64_t bs, int64_t m) {
+    return bs % sw.k_cap == 0 && bs / sw.k_cap <= sw.b_panels && bs <= 2048 && m <= sw.mb_cap;
+}
 
 int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
                        float* tmp, const SplitWork& sw, hipStream_t s) {
-    const int64_t bs = ti.bs, ldp = 4 * sw.k_cap;
-    NNGP_REQUIRE(sw.l_ready && bs == sw.k_cap && m <= sw.mb_cap, "trsm_rlt_blocks_h3: split copy of L not available");
+    const int64_t bs = ti.bs, kc = sw.k_cap, ldp = 4 * kc;
+    NNGP_REQUIRE(sw.l_ready && h3_step_ok(sw, bs, m), "trsm_rlt_blocks_h3: split copy of L not available");
     for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
         const int64_t sz = (np - o < bs) ? np - o : bs;
         const int64_t rest = np - o - sz;
         NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
         if (rest > 0 && sz == bs && h3_worth(m, rest)) {
-            NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s));
-            NNGP_TRY(launch_gemm_nt_h3(b + o + sz, ldb, sw.planes_b, sw.planes + j * sw.col_stride + (o + sz) * ldp, ldp, m,
-                                       rest, sz, -1.0f / sw.scale, 1.0f, false, 0, sw.counters, 0, s, sw.row_inv));
+            NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s, sw.col_stride));
+            // rows o + sz .. of L, columns [o, o + sz): block columns o / kc .. of the factor's split copy, rows at their global index
+            NNGP_TRY(h3_step_update(b + o + sz, ldb, m, rest, sz, sw.planes + (o / kc) * sw.col_stride + (o + sz) * ldp, sw, s));
         } else {
             NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
                                             hipMemcpyDeviceToDevice, s));
@@ -365,8 +391,8 @@ int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t
 
 int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,
                        float* tmp, const SplitWork& sw, hipStream_t s) {
-    const int64_t bs = ti.bs, ldp = 4 * sw.k_cap;
-    NNGP_REQUIRE(sw.lt_ready && bs == sw.k_cap && m <= sw.mb_cap, "trsm_rut_blocks_h3: split copy of L^T not available");
+    const int64_t bs = ti.bs, kc = sw.k_cap, ldp = 4 * kc;
+    NNGP_REQUIRE(sw.lt_ready && h3_step_ok(sw, bs, m), "trsm_rut_blocks_h3: split copy of L^T not available");
     const int64_t nblk = (np + bs - 1) / bs;
     for (int64_t j = nblk - 1; j >= 0; --j) {
         const int64_t o = j * bs;
@@ -375,9 +401,9 @@ int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_
         // lt == nullptr: no float32 copy of L^T exists (it is only built for the float32 path) -- every update, also the
         // few-tile ones and the tail block, goes through the split copy: +0.07 ms per small step, -1.8 ms of transposition
         if (o > 0 && (lt == nullptr || (sz == bs && h3_worth(m, o)))) {
-            NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s));
-            NNGP_TRY(launch_gemm_nt_h3(b, ldb, sw.planes_b, sw.planes_t + j * sw.col_stride, ldp, m, o, sz, -1.0f / sw.scale, 1.0f,
-                                       false, 0, sw.counters, 0, s, sw.row_inv));
+            NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s, sw.col_stride));
+            // block rows o / kc .. of the split copy of L^T: out_j[r][k] = L[j kc + k][r], rows r < o
+            NNGP_TRY(h3_step_update(b, ldb, m, o, sz, sw.planes_t + (o / kc) * sw.col_stride, sw, s));
         } else {
             NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
                                             hipMemcpyDeviceToDevice, s));

@@ -130,6 +130,13 @@ class GPModel:
         dinv = _wrap_device(d.value, (np_ // 128) * 128 * 128, self.device, "<f4").view(np_ // 128, 128, 128)
         return a32, dinv
 
+    def apply_factor(self, b, both_halves: bool = False):
+        """b [rows, n] float32 CUDA tensor (contiguous), overwritten with ``b L^-T`` (``both_halves``: ``b (L L^T)^-1``) through the
+        blocked solves the posterior takes for a block of that many rows (nngp_model_apply_factor)."""
+        assert b.is_cuda and b.dtype == torch.float32 and b.is_contiguous() and b.dim() == 2
+        self._check(self.lib.nngp_model_apply_factor(self.handle, b.data_ptr(), b.shape[0], 1 if both_halves else 0, _lib.stream_ptr()))
+        return b
+
     def solve(self, max_iters: int = 0, tol: float = 0.0):
         self._check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))
 

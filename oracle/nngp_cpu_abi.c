@@ -455,6 +455,7 @@ int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* va
 }
 
 int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, void* stream) { (void)a; (void)lda; (void)n; (void)x; (void)y; (void)diag_add; (void)stream; NOT_HERE("nngp_symv_f64"); }
+int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode, void* stream) { (void)m; (void)b; (void)rows; (void)mode; (void)stream; NOT_HERE("nngp_model_apply_factor"); }
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t n, void* stream) { (void)b; (void)ldb; (void)m; (void)l; (void)ldl; (void)dinv; (void)n; (void)stream; NOT_HERE("nngp_trsm_rlt_f32"); }
 int nngp_comm_unique_id(void* id128) { (void)id128; NOT_HERE("nngp_comm_unique_id"); }
 int nngp_comm_create(nngp_comm** out, const void* id128, int32_t world, int32_t rank) { (void)out; (void)id128; (void)world; (void)rank; NOT_HERE("nngp_comm_create"); }

@@ -494,6 +494,38 @@ def test_trsm_right_lower_transposed():
     assert resid < 5e-4, resid
 
 
+@pytest.mark.parametrize("n,rows", [(9300, 1024), (10800, 600), (12288, 256), (8192, 1000)])
+def test_blocked_solves_of_the_posterior_against_scipy(n, rows):
+    """The posterior's blocked triangular solves (round 4: 2048-column steps -- two 1024-column panels per step of the
+    split-float16 updates -- from N = 8192 on; reference: the cho_solve inside predict_fn, train.py:157-158) against
+    scipy.linalg.solve_triangular on the model's own float32 factor, at sizes that are not multiples of the step (9300 -> 9344 =
+    4 x 2048 + 1024 + 128; 10800 -> 10880 = 5 x 2048 + 640), row counts that are not multiples of the tile, and one block below
+    the float16 path's row threshold.  Gate: the residual  X L^T - B  against the scale |X| |L|^T of its terms (what a
+    backward-stable float32 substitution leaves is ~ n eps of that; the blocked form multiplies by inverted diagonal blocks, so a
+    few times more), and the solution against the float64 solve within that residual's reach."""
+    import scipy.linalg as sla
+    x, y = synth.synthetic_queries(n, 24, seed=51)
+    model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    a32, _ = model.factor_buffers()
+    L = torch.tril(a32[:n, :n]).double().cpu().numpy()
+    rng = np.random.default_rng(n + rows)
+    B = rng.standard_normal((rows, n)).astype(np.float32) * (1.0 + 10.0 * rng.random((rows, 1)).astype(np.float32))
+    # forward half
+    X = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev())).cpu().numpy().astype(np.float64)
+    scale = np.abs(X) @ np.abs(L).T
+    res = np.abs(X @ L.T - B)
+    assert (res / scale).max() < 2e-5, (res / scale).max()
+    Xref = sla.solve_triangular(L, B.astype(np.float64).T, lower=True).T
+    assert np.linalg.norm(X - Xref) <= 2e-3 * np.linalg.norm(Xref), np.linalg.norm(X - Xref) / np.linalg.norm(Xref)
+    # both halves: Z L L^T = B
+    Z = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev()), both_halves=True).cpu().numpy().astype(np.float64)
+    Y = Z @ L                       # should solve Y L^T = B like X
+    scale2 = np.abs(Y) @ np.abs(L).T + (np.abs(Z) @ np.abs(L)) @ np.abs(L).T
+    res2 = np.abs(Y @ L.T - B)
+    assert (res2 / scale2).max() < 2e-5, (res2 / scale2).max()
+    model.close()
+
+
 # ---------------------------------------------------------------------------- fit / predict (a3, a4)
 def _fit_and_check(x, y, xt, n_relu=1, get="nngp", w=1.0, b=0.0):
     a = o.make_arch(n_relu, w, b)
