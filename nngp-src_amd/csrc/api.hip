@@ -924,7 +924,7 @@ int nngp_model_factor(nngp_model* m, void* stream) {
     set_split_scale(m);
     for (int attempt = 0;; ++attempt) {
         NNGP_TRY(nngp_model_factor_begin(m, stream));
-        NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->ld, m->dinv, m->clamped, (float)(0.25 * m->reg_fac), m->la, &m->split, s));
+        NNGP_TRY(potrf_lookahead_f32(m->a32, m->np, m->ld, m->dinv, m->clamped, (float)(0.25 * m->reg_fac), m->la, &m->split, s, &m->tri));
         int32_t cl = 0;
         NNGP_HIP_CHECK(hipMemcpyAsync(&cl, m->clamped, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         NNGP_HIP_CHECK(hipStreamSynchronize(s));

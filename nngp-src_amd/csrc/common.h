@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
 //   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
 //   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
 //   8  round 4, grouped Cholesky: 1 = the round-3 schedule (panel solves on the update stream); 2 = bulk panel solves on the panel
-//      stream itself; 4 = no early part of the next group's first diagonal-block update; 8 = helper grids on the panel stream
+//      stream itself; 4 = early part of the next group's first diagonal-block update on its own stream; 8 = helper grids behind the bulk solves; 16 = a far chunk's next-column region and its share in one launch
 //   9  round 4, posterior solves: block columns per step of the blocked triangular solves (default 2; 1 = round 3)
 #ifdef NNGP_TIMING_KNOBS
 extern std::atomic<int> g_knobs[16];
@@ -175,6 +175,8 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     hipStream_t panel = nullptr, update = nullptr;
     hipStream_t bulk = nullptr;  // round 4: the panel solves of the rows beyond the next diagonal block (above the update stream's priority)
     hipStream_t aux = nullptr;   // round 4: the early part of a group's product onto the next group's first diagonal block
+    hipStream_t side = nullptr;  // round 4: lowest priority -- the inverses of finished diagonal blocks under the chain-bound last block columns
+    hipEvent_t ev_side_done = nullptr;
     bool masked = false;  // streams own disjoint CU sets (hipExtStreamCreateWithCUMask)
     hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
     hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};
@@ -184,6 +186,8 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     // group's first diagonal-block update is in place
     hipEvent_t ev_far[kMaxSteps] = {}, ev_near[kMaxSteps] = {}, ev_tc[kMaxSteps] = {}, ev_tb[kMaxSteps] = {}, ev_split[kMaxSteps] = {},
                ev_gp[kMaxSteps] = {};
+    hipEvent_t ev_c1[kMaxSteps] = {};     // the far chunk's launch over the next block column has been issued (and everything before it)
+    hipEvent_t ev_chain[kMaxSteps] = {};  // not owned: ev_c1[k] or ev_far[k], whichever the chain's next links wait for
     hipEvent_t ev_bulk_done = nullptr;
     // live timing of the split-float16 trailing updates (nngp_model_update_timer): event pairs around each launch
     static constexpr int kMaxTimed = 320;  // split-float16 update launches of one factorisation (grouped form: ~3 per block column)
@@ -195,8 +199,9 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
 };
 int lookahead_create(LookAhead** out);
 void lookahead_destroy(LookAhead* la);
+struct TriInv;
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
-                        LookAhead* la, SplitWork* sw, hipStream_t user);
+                        LookAhead* la, SplitWork* sw, hipStream_t user, TriInv* ti = nullptr);  // ti: invert finished diagonal blocks on the way
 constexpr int64_t kLookAheadNb = 1024;  // block-column width of the look-ahead Cholesky
 constexpr int kLookAheadGroup = 4;      // block columns per deep-K far update (potrf.hip, grouped form)
 int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, int64_t o,
@@ -268,9 +273,12 @@ struct TriInv {
     float* xinv = nullptr;     // [nblk][bs*bs]  X_J = L_JJ^-1 (lower triangular)
     float* partial = nullptr;  // [bs/128][np]   column partial sums of the backward sweep
     float* tmp = nullptr;      // [bs]
+    int64_t done_blocks = 0;   // blocks [0, done_blocks) of the CURRENT factor are already inverted (set by the look-ahead Cholesky,
+                               // consumed -- and reset -- by triinv_build)
 };
 int64_t triinv_block(int64_t np);
 int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, hipStream_t s);
+int triinv_build_range(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, int64_t j0, int64_t j1, hipStream_t s);
 int trsm_rlt_blocks_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
                         float* tmp, hipStream_t s);
 int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64_t ld, const TriInv& ti, int64_t np,

@@ -619,13 +619,14 @@ int lookahead_create(LookAhead** out) {
         const int mid = (least + greatest) / 2;
         if (hipStreamCreateWithPriority(&la->bulk, hipStreamNonBlocking, mid != least ? mid : greatest) != hipSuccess) la->bulk = nullptr;
         if (hipStreamCreateWithPriority(&la->aux, hipStreamNonBlocking, greatest) != hipSuccess) la->aux = nullptr;
+        if (hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, least) != hipSuccess) la->side = nullptr;
     }
-    hipEvent_t* all[4] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done, &la->ev_bulk_done};
+    hipEvent_t* all[5] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done, &la->ev_bulk_done, &la->ev_side_done};
     for (auto e : all)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
     for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
-        hipEvent_t* per[10] = {&la->ev_panel[i], &la->ev_col[i], &la->ev_chunk[i], &la->ev_helper[i], &la->ev_far[i],
-                               &la->ev_near[i],  &la->ev_tc[i],  &la->ev_tb[i],    &la->ev_split[i],  &la->ev_gp[i]};
+        hipEvent_t* per[11] = {&la->ev_panel[i], &la->ev_col[i], &la->ev_chunk[i], &la->ev_helper[i], &la->ev_far[i],
+                               &la->ev_near[i],  &la->ev_tc[i],  &la->ev_tb[i],    &la->ev_split[i],  &la->ev_gp[i], &la->ev_c1[i]};
         for (auto e : per)
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 set_error("hipEventCreate failed");
@@ -645,11 +646,13 @@ void lookahead_destroy(LookAhead* la) {
     (void)hipStreamDestroy(la->update);
     if (la->bulk) (void)hipStreamDestroy(la->bulk);
     if (la->aux) { (void)hipStreamSynchronize(la->aux); (void)hipStreamDestroy(la->aux); }
+    if (la->side) { (void)hipStreamSynchronize(la->side); (void)hipStreamDestroy(la->side); }
+    if (la->ev_side_done) (void)hipEventDestroy(la->ev_side_done);
     (void)hipEventDestroy(la->ev_in); (void)hipEventDestroy(la->ev_panel_done); (void)hipEventDestroy(la->ev_update_done);
     if (la->ev_bulk_done) (void)hipEventDestroy(la->ev_bulk_done);
     for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
-        hipEvent_t per[10] = {la->ev_panel[i], la->ev_col[i], la->ev_chunk[i], la->ev_helper[i], la->ev_far[i],
-                              la->ev_near[i],  la->ev_tc[i],  la->ev_tb[i],    la->ev_split[i],  la->ev_gp[i]};
+        hipEvent_t per[11] = {la->ev_panel[i], la->ev_col[i], la->ev_chunk[i], la->ev_helper[i], la->ev_far[i],
+                              la->ev_near[i],  la->ev_tc[i],  la->ev_tb[i],    la->ev_split[i],  la->ev_gp[i], la->ev_c1[i]};
         for (auto e : per)
             if (e) (void)hipEventDestroy(e);
     }
@@ -920,7 +923,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
 // 128-blocks (operands of the fused solves) alternate between two buffers: Tb_k may still be reading one while the panel stream
 // prepares block column k + 1.
 static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor, LookAhead* la,
-                                      SplitWork* sw, hipStream_t user, int64_t nb, int D) {
+                                      SplitWork* sw, hipStream_t user, int64_t nb, int D, TriInv* ti) {
     la->tu_count = 0;
     hipStream_t SP = la->panel, SU = la->update, SB = (NNGP_KNOB(8) & 2) ? la->panel : la->bulk;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
@@ -933,7 +936,7 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
     const int reserve = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
     const int64_t lead0 = 64;  // columns of block column 0 that stay on the float32 MFMA (see potrf_lookahead_f32)
     const bool use_helper = !(NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) && reserve >= 8 && reserve % 8 == 0;
-    const bool early_gp = !(NNGP_KNOB(8) & 4);
+    const bool early_gp = (NNGP_KNOB(8) & 4) != 0;  // measured: one more CG iteration (6 instead of 5 at N = 32768) -- off
     auto plane_rows = [&](int col, int64_t row) { return sw->planes + (int64_t)col * sw->col_stride + row * ldp; };
     auto width = [&](int64_t col0) { return (n - col0 < nb) ? n - col0 : nb; };
     FarWork far;
@@ -1003,7 +1006,7 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         return 0;
     };
     // the pieces of the pending far update that belong to step `step` (block column gend + i of the next group is being factored)
-    auto far_step = [&](int step, bool* colrows_event) -> int {
+    auto far_step = [&](int step, bool* colrows_event, bool* c1_event) -> int {
         if (!far.active || far.next >= far.nchunks) return 0;
         const int i = far.next++;
         const int64_t r0 = far.r0;
@@ -1022,8 +1025,20 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
                 nreg = 0;
             }
         }
-        const int64_t c1 = r0 + (int64_t)(i + 1) * nb;  // column gend + i + 1, if it belongs to the next group
+        // column gend + i + 1 of the next group in a launch of its own: the chain (G, P of that column) waits for this launch only,
+        // not for the chunk's share of the columns beyond -- the diagonal-block chain then runs a whole step ahead of the update
+        // stream and the bulk solve of a block column has the following far chunk to hide under (debug key 8 = 16: one launch)
+        const int64_t c1 = r0 + (int64_t)(i + 1) * nb;
+        const bool split_c1 = !(NNGP_KNOB(8) & 16) && step >= 0;
         if (c1 < n && i + 1 < D) add(c1, c1, width(c1), 0);
+        if (split_c1 && nreg > 0) {
+            NNGP_TRY(far_launch(reg, nreg, step, false));
+            nreg = 0;
+        }
+        if (split_c1) {
+            NNGP_HIP_CHECK(hipEventRecord(la->ev_c1[step], SU));
+            *c1_event = true;
+        }
         // shares are dealt from the LAST chunk backwards: the early chunks already carry the next group's own columns
         const int si = far.nchunks - 1 - i;
         if (far.share_lo[si + 1] > far.share_lo[si]) add(far.share_lo[si], far.share_lo[si], far.share_lo[si + 1] - far.share_lo[si], 0);
@@ -1032,6 +1047,8 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
     };
 
     int rc = 0;
+    bool side_used = false;
+    constexpr int kTriInvTail = 7;  // block columns from the end where the finished blocks' inverses are issued
     for (int k = 0; k < nblk && rc == 0; ++k) {
         const int64_t o = (int64_t)k * nb;
         const int64_t nbk = width(o);
@@ -1041,15 +1058,33 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         const int g0 = (k / D) * D;
         const int gend = (g0 + D < nblk) ? g0 + D : nblk;
         // ---- panel stream: P_k ----
-        if (k > 0) NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_far[k - 1], 0));
+        if (k > 0) NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_chain[k - 1], 0));
         rc = potrf_rec(akk, nbk, ld, dk, clamped, pivot_floor, SP);
         NNGP_HIP_CHECK(hipEventRecord(la->ev_panel[k], SP));
         if (rc != 0) break;
+        // The inverted diagonal blocks of the blocked solves (solve.hip, triinv_build): from here on the chain of diagonal-block
+        // factorisations bounds the factorisation and most of the chip idles -- the blocks of the block columns behind us are
+        // inverted now, on the lowest-priority stream, instead of after the factorisation (debug key 8 = 32: not here).
+        if (ti != nullptr && la->side != nullptr && !(NNGP_KNOB(8) & 32) && k == nblk - kTriInvTail && ti->bs % nb == 0 && k >= 2) {
+            const int64_t jdone = ((int64_t)(k - 1) * nb) / ti->bs;  // block columns 0 .. k - 2 are final (P_{k-1} has been waited for by Tc_{k-1})
+            if (jdone > 0) {
+                NNGP_HIP_CHECK(hipStreamWaitEvent(la->side, la->ev_tc[k - 1], 0));
+                rc = triinv_build_range(a, ld, dinv, n, *ti, 0, jdone, la->side);
+                if (rc != 0) break;
+                NNGP_HIP_CHECK(hipEventRecord(la->ev_side_done, la->side));
+                ti->done_blocks = jdone;
+                side_used = true;
+            }
+        }
         // ---- update stream: this step's share of the previous group's far update ----
-        bool colrows = false;
+        bool colrows = false, c1ev = false;
         ph.on = false;
-        rc = far_step(k, &colrows);
+        rc = far_step(k, &colrows, &c1ev);
         NNGP_HIP_CHECK(hipEventRecord(la->ev_far[k], SU));
+        // what the chain's next links (G_k, P_{k+1}) wait for: everything on the update stream that touches diagonal block k + 1 --
+        // the near updates up to N_{k-1} and this step's launch over column k + 1 (or, at a group's end, the whole chunk: the
+        // previous group's shares cover the next group's first diagonal block)
+        la->ev_chain[k] = (c1ev && k + 1 < gend) ? la->ev_c1[k] : la->ev_far[k];
         if (rc != 0 || m == 0) break;
         // ---- the panel solves: Tc_k on the panel stream, Tb_k on the bulk stream ----
         const int64_t nb2 = width(o + nbk);
@@ -1082,10 +1117,10 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         }
         NNGP_HIP_CHECK(hipEventRecord(la->ev_tb[k], SB));
         // The far chunk's helper grid: the `reserve` compute units the chunk's own grid leaves free carry the diagonal-block chain (a
-        // workgroup at a time) and the bulk solve; once Tb_k is through, that many workgroups join the chunk from the bulk stream
-        // (debug key 8 = 8: from the panel stream, behind Tc_k, as in round 3 -- there they compete with Tb_k for the same units).
+        // workgroup at a time) and the bulk solve; that many workgroups join the chunk from a stream of their own (debug key 8 = 8:
+        // from the bulk stream, behind Tb_k).  Not from the panel stream as in round 3: the chain no longer waits for the chunk.
         if (ph.on) {
-            hipStream_t SH = (NNGP_KNOB(8) & 8) ? SP : SB;
+            hipStream_t SH = (NNGP_KNOB(8) & 8) ? SB : (la->aux != nullptr ? la->aux : SB);
             NNGP_HIP_CHECK(hipStreamWaitEvent(SH, la->ev_chunk[ph.step], 0));
             rc = launch_gemm_nt_h3r(a, ld, plane_rows(ph.kl, 0), plane_rows(ph.kl, 0), ldp, sw->col_stride, ph.np, ph.lead, ph.reg, ph.nreg, nb,
                                     ascale, 1.0f, true, sw->counters, reserve, SH, nullptr, 2);
@@ -1096,7 +1131,7 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         }
         // ---- G_k, the product of the rows just solved onto the next diagonal block.  This step's far chunk carries that block's
         // share of the previous group (same C tiles): the product waits for it, as P_{k+1} has to anyway. ----
-        NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_far[k], 0));
+        NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_chain[k], 0));
         if (k + 1 < gend) {
             rc = launch_gemm_nt_f32(c, ld, below, ld, below, ld, nb2, nb2, nbk, -1.0f, 1.0f, true, SP);
         } else {
@@ -1169,8 +1204,8 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
             }
         }
     }
-    bool dummy = false;
-    while (rc == 0 && far.active) rc = far_step(-1, &dummy);  // (nothing is left when the loop ran to the last block column)
+    bool dummy = false, dummy2 = false;
+    while (rc == 0 && far.active) rc = far_step(-1, &dummy, &dummy2);  // (nothing is left when the loop ran to the last block column)
     if (rc == 0) sw->l_ready = true;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, SP));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, SU));
@@ -1178,11 +1213,13 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
     NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_update_done, 0));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_bulk_done, SB));
     NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_bulk_done, 0));
+    if (side_used) NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_side_done, 0));
     return rc;  // (the aux stream's last product was waited for by the panel stream)
 }
 
 int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, float pivot_floor,
-                        LookAhead* la, SplitWork* sw, hipStream_t user) {
+                        LookAhead* la, SplitWork* sw, hipStream_t user, TriInv* ti) {
+    if (ti != nullptr) ti->done_blocks = 0;
     NNGP_REQUIRE(n > 0 && n % TB == 0, "potrf_f32: n must be a positive multiple of %d (got %lld)", TB, (long long)n);
     // block-column width: 1024 measured best at N = 32768 (119.4 ms; 2048: 121.3, 4096: 123.2, recursion only: 125)
     int64_t nb = NNGP_KNOB(1) > 0 ? (int64_t)NNGP_KNOB(1) : kLookAheadNb;
@@ -1203,7 +1240,7 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     const int group = (NNGP_KNOB(2) >= 11 && NNGP_KNOB(2) <= 26) ? NNGP_KNOB(2) - 10 : (NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) ? NNGP_KNOB(2) - 30 : kLookAheadGroup;
     if (h3 && group > 1 && nb == 1024 && (NNGP_KNOB(2) == 0 || NNGP_KNOB(2) >= 11) && NNGP_KNOB(3) == 0 && ld % 4 == 0) {
         if (la->bulk != nullptr && !(NNGP_KNOB(8) & 1))
-            return potrf_lookahead_grouped_v4(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
+            return potrf_lookahead_grouped_v4(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group, ti);
         return potrf_lookahead_grouped(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
     }
     la->tu_count = 0;

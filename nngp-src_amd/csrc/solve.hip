@@ -281,23 +281,35 @@ int64_t triinv_block(int64_t np) {
 
 // Inverts the diagonal blocks (size bs, tail np % bs) of the float32 factor: T_J = L_JJ^-T by a batched
 // triangular solve against the identity (MFMA GEMMs), X_J = T_J^T.  Used by the blocked TRSVs below.
-int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, hipStream_t s) {
+// Blocks [j0, j1) only (round 4: the look-ahead Cholesky inverts the blocks of its finished block columns on a low-priority
+// stream while its last, chain-bound block columns leave most of the chip idle; nngp_model_factor_end does the rest).
+int triinv_build_range(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, int64_t j0, int64_t j1, hipStream_t s) {
     const int64_t bs = ti.bs;
     NNGP_REQUIRE(bs % TB == 0 && bs > 0 && np % TB == 0, "triinv_build: bad block size");
-    const int64_t nfull = np / bs, tail = np % bs;
-    const int64_t total = (nfull + (tail ? 1 : 0)) * bs * bs;
-    hipLaunchKernelGGL(k_set_identity_blocks, dim3(blocks256(total)), dim3(256), 0, s, ti.tinv, bs, total);
-    if (nfull > 0)
-        NNGP_TRY(trsm_rlt_batched(ti.tinv, bs, bs * bs, bs, l, ld, bs * (ld + 1), dinv, (bs / TB) * TB * TB, bs,
-                                  (int)nfull, s));
-    if (tail > 0) {
+    const int64_t nfull = np / bs, tail = np % bs, nall = nfull + (tail ? 1 : 0);
+    if (j1 > nall) j1 = nall;
+    if (j0 >= j1) return 0;
+    const int64_t total = (j1 - j0) * bs * bs;
+    float* t0 = ti.tinv + j0 * bs * bs;
+    hipLaunchKernelGGL(k_set_identity_blocks, dim3(blocks256(total)), dim3(256), 0, s, t0, bs, total);
+    const int64_t jf = j1 < nfull ? j1 : nfull;  // full blocks in the range: [j0, jf)
+    if (jf > j0)
+        NNGP_TRY(trsm_rlt_batched(t0, bs, bs * bs, bs, l + j0 * bs * (ld + 1), ld, bs * (ld + 1), dinv + j0 * (bs / TB) * TB * TB,
+                                  (bs / TB) * TB * TB, bs, (int)(jf - j0), s));
+    if (tail > 0 && j1 == nall) {
         const int64_t o = nfull * bs;
         NNGP_TRY(trsm_rlt_f32(ti.tinv + nfull * bs * bs, bs, tail, l + o * (ld + 1), ld, dinv + (o / TB) * TB * TB, tail, s));
     }
-    hipLaunchKernelGGL(k_transpose_blocks, dim3((unsigned)(bs / 32), (unsigned)(bs / 32), (unsigned)(nfull + (tail ? 1 : 0))),
-                       dim3(256), 0, s, ti.tinv, ti.xinv, bs);
+    hipLaunchKernelGGL(k_transpose_blocks, dim3((unsigned)(bs / 32), (unsigned)(bs / 32), (unsigned)(j1 - j0)), dim3(256), 0, s, t0,
+                       ti.xinv + j0 * bs * bs, bs);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriInv& ti, hipStream_t s) {
+    const int64_t j0 = ti.done_blocks;  // already inverted for this factor (look-ahead Cholesky)
+    ti.done_blocks = 0;
+    return triinv_build_range(l, ld, dinv, np, ti, j0, (np + ti.bs - 1) / ti.bs, s);
 }
 
 // B[m, np] <- B L^-T with the inverted bs-blocks: per block column J one GEMM with X_J = L_JJ^-1 (out of place into

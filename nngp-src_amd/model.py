@@ -133,6 +133,7 @@ class GPModel:
     def apply_factor(self, b, both_halves: bool = False):
         """b [rows, n] float32 CUDA tensor (contiguous), overwritten with ``b L^-T`` (``both_halves``: ``b (L L^T)^-1``) through the
         blocked solves the posterior takes for a block of that many rows (nngp_model_apply_factor)."""
+        import torch
         assert b.is_cuda and b.dtype == torch.float32 and b.is_contiguous() and b.dim() == 2
         self._check(self.lib.nngp_model_apply_factor(self.handle, b.data_ptr(), b.shape[0], 1 if both_halves else 0, _lib.stream_ptr()))
         return b

@@ -348,30 +348,35 @@ def test_grouped_cholesky_matches_the_one_column_form(n):
 @pytest.mark.parametrize("n", [9300, 13440])
 def test_cholesky_schedule_with_the_panel_solves_off_the_update_stream(n):
     """Round 4's schedule of the grouped Cholesky (panel solves on the panel / bulk streams, trailing updates alone on the update
-    stream, the far chunk of a group's first step in two launches) against round 3's (debug key 8 = 1: everything but the
-    diagonal-block factorisations in line on the update stream).  With the early part of the next group's first diagonal-block
-    update switched off (key 8 = 4) every tile sees the same arithmetic in the same order: the factors must agree BIT FOR BIT --
-    any read-modify-write race between the four streams would show here.  The default (early part on) differs by float32
-    rounding in those diagonal blocks only; alpha, the float64 CG answer, agrees to 1e-9 and the CG takes the same iterations."""
+    stream, far chunks in up to three launches, finished diagonal blocks inverted on a side stream under the last block columns)
+    against round 3's (debug key 8 = 1: everything but the diagonal-block factorisations in line on the update stream).  Every tile
+    sees the same arithmetic in the same order: the factors, alpha and the posterior of a block of queries must agree BIT FOR BIT
+    -- any read-modify-write race between the five streams would show here.  Also with the far chunks in one launch (key 8 = 16)
+    and the inverses after the factorisation (32).  The variant with the early part of the next group's first diagonal-block
+    update on its own stream (key 8 = 4; off: it costs a CG iteration at N = 32768) differs by float32 rounding in those
+    diagonal blocks only; alpha, the float64 CG answer, agrees to 1e-9."""
     from nngp_src_amd import _lib
     x, y = synth.synthetic_queries(n, 48, seed=41)
+    xt, _ = synth.synthetic_queries(300, 48, seed=42)
     lib = _lib.load(knobs=True)
     res = {}
-    for key8 in (1, 4, 4, 0, 0):
+    for key8 in (1, 0, 0, 16, 32, 4):
         lib.nngp_debug_set(8, key8)
         try:
             mdl = GPModel(n, 48, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
             a32, _ = mdl.factor_buffers()
-            res.setdefault(key8, []).append((mdl.info(), mdl.alpha().cpu().numpy().copy(), torch.tril(a32[:n, :n]).clone()))
+            mean, var = mdl.predict(xt, cov="diag")
+            res.setdefault(key8, []).append((mdl.info(), mdl.alpha().cpu().numpy().copy(), torch.tril(a32[:n, :n]).clone(), mean, var))
             mdl.close()
         finally:
             lib.nngp_debug_set(8, 0)
-    (i3, a3, l3) = res[1][0]
-    for (i4, a4, l4) in res[4]:
-        assert i4["clamped_pivots"] == 0
-        assert torch.equal(l3, l4) and np.array_equal(a3, a4)
-    (i0, a0, l0), (_, a0b, l0b) = res[0]
-    assert torch.equal(l0, l0b) and np.array_equal(a0, a0b)
+    (i3, a3, l3, m3, v3) = res[1][0]
+    for key8 in (0, 16, 32):
+        for (i4, a4, l4, m4, v4) in res[key8]:
+            assert i4["clamped_pivots"] == 0
+            assert torch.equal(l3, l4) and np.array_equal(a3, a4), key8
+            assert np.array_equal(m3, m4) and np.array_equal(v3, v4), key8  # the inverted blocks too
+    (i0, a0, l0, _, _) = res[4][0]
     assert i0["clamped_pivots"] == 0 and i0["rel_residual"] < 1e-9 and abs(i0["refine_iters"] - i3["refine_iters"]) <= 1
     assert np.linalg.norm(a0 - a3) <= 1e-9 * np.linalg.norm(a3)
     assert (l0 - l3).abs().max().item() <= 2e-3 * l3.abs().max().item()
