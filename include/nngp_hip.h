@@ -295,9 +295,11 @@ int nngp_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, doub
 /* Pool scoring of the active-learning loop on the device (reference: active/ActiveLearner.py:43-55, active_test):
  * score_i = sqrt(max(var_i, 0)) / max_j mean[j * ny] (np.max(pred_mean, 0) of the single output column).
  *   biased = 0: the `count` largest scores in ascending order of score -- np.argsort(score)[-count:];
- *   biased = 1: `count` indices drawn without replacement with probability proportional to the score (the reference's
- *               random.choice(..., replace=False, p=score / sum(score))), as a Gumbel top-k on the counter-based generator
- *               u_i = splitmix64(seed, i) >> 11: the same draw on every device and in the host build, in draw order.
+ *   biased = 1: `count` indices drawn without replacement with probability proportional to the score, AS THE REFERENCE DRAWS THEM --
+ *               jax.random.choice(PRNGKey(seed), m, (count,), replace=False, p=score / sum(score)) of jax 0.3.23 (nngp.yaml:78):
+ *               Gumbel top-k, argsort(-gumbel - log p)[:count], with u_i from Threefry-2x32-20 on the counter pair (i, m + i) under the
+ *               key (seed >> 32, seed & 0xffffffff) -- restated in nngp-src_amd/jaxrand.py, pinned by the Random123 known-answer
+ *               vectors; the same draw on every device and in the host build, in draw order.
  * mean [m, ny], var [m], indices [count] are device pointers (host pointers in the host build): only `count` indices have to
  * travel to the host.  count <= m. */
 int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased,

@@ -5,9 +5,13 @@ move the `budget` most uncertain (or std-proportionally sampled) pool queries in
 The first fit is a full kernel build + Cholesky on the GPU; every later round only builds the kernel rows of the
 queries it adds and EXTENDS the factor (``GPModel.append`` / ``nngp_model_append``: a blocked triangular solve against
 the existing factor plus a small Cholesky, ~b N^2 flops instead of N^3/3), then re-solves alpha in float64.  The model
-handle is sized for the final training set, so nothing is reallocated between iterations.  Differences from the reference, none of which change
-the deterministic path: only diag(cov) is requested; the biased sampler draws with NumPy's PCG64 seeded with 10
-where the reference uses jax.random.PRNGKey(10) (threefry) -- the draws differ, the distribution does not.
+handle is sized for the final training set, so nothing is reallocated between iterations.  Differences from the reference: only
+diag(cov) is requested.  The biased sampler -- the reference's default, ``--biased_sample True`` (active_train.py:62) -- restates
+``jax.random.choice(PRNGKey(10), n, (k,), replace=False, p=std_prob)`` step by step (``jaxrand.py``: Threefry-2x32-20 -> 52-bit
+uniforms -> Gumbel top-k), on the device (``nngp_pool_select``), in the host build and in the NumPy fallback below: the draw is the
+reference's draw index for index wherever jax's own ``log`` and ours round alike (pinned by the Random123 vectors of Threefry, not
+against jax itself, which is not installable here).  NaN scores (a NaN variance or mean): the reference's argsort puts NaN LAST,
+i.e. its top-k path would select them first and its biased path never; here a NaN score never wins in either path.
 """
 from __future__ import annotations
 
@@ -18,7 +22,7 @@ from .util import PredictionStatistics
 
 
 class ActiveLearner(object):
-    def __init__(self, args=None, budget=1000, active_iters=3, kernel_type="nngp", biased_sample=False):
+    def __init__(self, args=None, budget=1000, active_iters=3, kernel_type="nngp", biased_sample=True):
         self.args = args
         self.budget = getattr(args, "budget", budget)
         self.active_iters = getattr(args, "active_iters", active_iters)
@@ -58,7 +62,7 @@ class ActiveLearner(object):
                 return self._model.predict(x_test, cov="diag" if compute_cov == "diag" else "full")
             return self._model.predict(x_test, cov=False)
 
-        predict_fn.model = self._model  # active_test scores the pool on the device through it
+        predict_fn.learner = self  # active_test scores the pool on the device through the learner's CURRENT model
         return predict_fn
 
     # -- reference: ActiveLearner.test (ActiveLearner.py:33-40) --
@@ -73,19 +77,21 @@ class ActiveLearner(object):
     # -- reference: ActiveLearner.active_test (ActiveLearner.py:43-55) --
     def active_test(self, predict_fn, X_test, kernel_type="nngp"):
         num_test = X_test.shape[0]
-        model = getattr(predict_fn, "model", None)
+        num_select = self.budget if num_test > self.budget else num_test
+        # the model is looked up NOW: a predict_fn kept across a train() that replaced the model would hold a closed handle
+        model = self._model if getattr(predict_fn, "learner", None) is self else None
         if model is not None and num_test > 0:
+            assert kernel_type == model.get, "active_test: the fitted model is a %r posterior" % model.get
             # std / max(mean), top-`budget` or the std-proportional draw, all on the GPU: only the indices come back
-            return model.select_pool(X_test, self.budget if num_test > self.budget else num_test, biased=self.biased_sample, seed=10)
+            return model.select_pool(X_test, num_select, biased=self.biased_sample, seed=10)
         pred_mean, pred_var = predict_fn(x_test=X_test, get=kernel_type, compute_cov="diag")
         pred_std = np.sqrt(np.maximum(pred_var, 0.0))
         pred_std = pred_std / np.max(pred_mean, 0)
-        num_test = X_test.shape[0]
         pred_std = np.reshape(pred_std, (num_test,))
-        num_select = self.budget if num_test > self.budget else num_test
         if self.biased_sample:
+            from .jaxrand import choice_without_replacement
             std_prob = pred_std / np.sum(pred_std)
-            return np.random.default_rng(10).choice(num_test, size=num_select, replace=False, p=std_prob)
+            return choice_without_replacement(10, num_test, num_select, std_prob)
         return np.argsort(pred_std)[-num_select:]
 
     # -- reference: ActiveLearner.merge_data (ActiveLearner.py:57-65) --

@@ -1642,8 +1642,12 @@ int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode,
     const int64_t mp = round_up(rows, TB), np = m->np, n = m->n;
     NNGP_HIP_CHECK(hipMemsetAsync(m->b32, 0, sizeof(float) * mp * np, s));
     NNGP_HIP_CHECK(hipMemcpy2DAsync(m->b32, sizeof(float) * np, b, sizeof(float) * n, sizeof(float) * n, rows, hipMemcpyDeviceToDevice, s));
-    if (mode == 0) NNGP_TRY(apply_forward_f32(m, mp, s));
-    else NNGP_TRY(apply_inverse_f32(m, mp, s));
+    if (mode == 0) {
+        NNGP_TRY(apply_forward_f32(m, mp, s));
+    } else {
+        if (!use_split_solves(m, mp)) NNGP_TRY(ensure_lt(m, s));  // float32 L^T: only the float32 solve path reads it
+        NNGP_TRY(apply_inverse_f32(m, mp, s));
+    }
     NNGP_HIP_CHECK(hipMemcpy2DAsync(b, sizeof(float) * n, m->b32, sizeof(float) * np, sizeof(float) * n, rows, hipMemcpyDeviceToDevice, s));
     return 0;
 }

@@ -177,6 +177,7 @@ struct LookAhead {  // streams and events of the look-ahead Cholesky (one per mo
     hipStream_t aux = nullptr;   // round 4: the early part of a group's product onto the next group's first diagonal block
     hipStream_t side = nullptr;  // round 4: lowest priority -- the inverses of finished diagonal blocks under the chain-bound last block columns
     hipEvent_t ev_side_done = nullptr;
+    int prio_levels = 0;         // stream priority levels of the device (the side stream needs three)
     bool masked = false;  // streams own disjoint CU sets (hipExtStreamCreateWithCUMask)
     hipEvent_t ev_in = nullptr, ev_panel_done = nullptr, ev_update_done = nullptr;
     hipEvent_t ev_panel[kMaxSteps] = {}, ev_col[kMaxSteps] = {};

@@ -660,7 +660,29 @@ __device__ __forceinline__ uint64_t splitmix64_dev(uint64_t seed, uint64_t idx) 
     return z ^ (z >> 31);
 }
 
-// key_i = score_i (top-k) or log(score_i) + Gumbel(u_i) (score-proportional draw without replacement); one workgroup
+// Threefry-2x32, 20 rounds (Salmon et al. 2011; the generator behind jax.random's PRNGKey): one block
+__device__ __forceinline__ void threefry2x32_dev(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+    const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    x0 += ks[0];
+    x1 += ks[1];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x0 += x1;
+            x1 = (x1 << rot[g & 1][r]) | (x1 >> (32 - rot[g & 1][r]));
+            x1 ^= x0;
+        }
+        x0 += ks[(g + 1) % 3];
+        x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+    }
+}
+
+// key_i = score_i (top-k), or log(score_i) + Gumbel(u_i): the score-proportional draw without replacement as the reference makes
+// it -- jax.random.choice(PRNGKey(seed), m, (count,), replace=False, p = score / sum(score)) = argsort(-gumbel - log p)[:count] with
+// u_i from Threefry on the counter pair (i, m + i), restated in nngp-src_amd/jaxrand.py (log p and log score differ by a constant:
+// the order is the same).  One workgroup.
 __global__ __launch_bounds__(1024) void k_pool_keys(const double* __restrict__ mean, int64_t m, int ny, const double* __restrict__ var,
                                                     int biased, uint64_t seed, double* __restrict__ key) {
     __shared__ double red[16];
@@ -675,15 +697,19 @@ __global__ __launch_bounds__(1024) void k_pool_keys(const double* __restrict__ m
         const double sc = sqrt(fmax(var[i], 0.0)) / mx;
         double k = sc;
         if (biased) {
-            double u = (double)(splitmix64_dev(seed, (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
-            if (u < 1.1102230246251565e-16) u = 1.1102230246251565e-16;
+            uint32_t x0 = (uint32_t)i, x1 = (uint32_t)(m + i);
+            threefry2x32_dev((uint32_t)(seed >> 32), (uint32_t)seed, x0, x1);
+            const uint64_t bits = ((((uint64_t)x0 << 32) | (uint64_t)x1) >> 12) | 0x3FF0000000000000ULL;
+            const double tiny = 2.2250738585072014e-308;
+            double u = __longlong_as_double((long long)bits) - 1.0;
+            u = fmax(tiny, u * (1.0 - tiny) + tiny);
             k = (sc > 0.0) ? log(sc) - log(-log(u)) : -INFINITY;
         }
         key[i] = (k == k) ? k : -INFINITY;  // NaN never wins
     }
 }
 
-// rank by counting: r_i = #{j : key_j > key_i, or key_j == key_i and j > i}; the `count` best go out
+// rank by counting: r_i = #{j : key_j > key_i, or key_j == key_i and j beats i on the tie rule}; the `count` best go out
 __global__ __launch_bounds__(256) void k_pool_rank(const double* __restrict__ key, int64_t m, int64_t count, int biased,
                                                    int64_t* __restrict__ out) {
     __shared__ double tile[256];
@@ -697,7 +723,9 @@ __global__ __launch_bounds__(256) void k_pool_rank(const double* __restrict__ ke
         const int lim = (m - j0 < 256) ? (int)(m - j0) : 256;
         for (int t = 0; t < lim; ++t) {
             const double kj = tile[t];
-            r += (kj > ki || (kj == ki && j0 + t > i)) ? 1 : 0;
+            // equal keys: the stable ascending argsort of the reference puts the larger index last -- the better place of
+            // np.argsort(score)[-count:], the worse of the biased draw's argsort(-gumbel - log p)[:count]
+            r += (kj > ki || (kj == ki && (biased ? j0 + t < i : j0 + t > i))) ? 1 : 0;
         }
     }
     if (i < m && r < count) out[biased ? r : count - 1 - r] = i;

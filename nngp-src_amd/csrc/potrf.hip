@@ -608,18 +608,23 @@ int lookahead_create(LookAhead** out) {
     if (!masked) {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        // Priorities (numerically lower = higher).  With three levels or more: the diagonal-block chain and the bulk panel solves on
+        // top, the trailing updates in the middle, and a lowest level for work that may only use what everything else leaves idle
+        // (the `side` stream: inverted blocks, digit planes, split copies cut under the chain-bound last block columns).  The bulk
+        // solves must outrank the update stream: their workgroups take the compute units a trailing-update launch gives back before
+        // the next launch's persistent grid settles there.  With two levels there is no side stream.
+        const bool three = least - greatest >= 2;
+        const int prio_update = three ? least - 1 : least;
         if (hipStreamCreateWithPriority(&la->panel, hipStreamNonBlocking, greatest) != hipSuccess ||
-            hipStreamCreateWithPriority(&la->update, hipStreamNonBlocking, least) != hipSuccess) {
+            hipStreamCreateWithPriority(&la->update, hipStreamNonBlocking, prio_update) != hipSuccess) {
             set_error("lookahead_create: hipStreamCreateWithPriority failed");
             delete la;
             return -1;
         }
-        // the bulk panel solves: any priority above the update stream's, so that their workgroups take the compute units a trailing
-        // update launch gives back before the next launch's persistent grid settles on them (debug key 1 = 2: the middle level)
-        const int mid = (least + greatest) / 2;
-        if (hipStreamCreateWithPriority(&la->bulk, hipStreamNonBlocking, mid != least ? mid : greatest) != hipSuccess) la->bulk = nullptr;
+        if (hipStreamCreateWithPriority(&la->bulk, hipStreamNonBlocking, greatest) != hipSuccess) la->bulk = nullptr;
         if (hipStreamCreateWithPriority(&la->aux, hipStreamNonBlocking, greatest) != hipSuccess) la->aux = nullptr;
-        if (hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, least) != hipSuccess) la->side = nullptr;
+        if (!three || hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, least) != hipSuccess) la->side = nullptr;
+        la->prio_levels = least - greatest + 1;
     }
     hipEvent_t* all[5] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done, &la->ev_bulk_done, &la->ev_side_done};
     for (auto e : all)
@@ -935,7 +940,10 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
     const float ascale = -1.0f / (sw->scale * sw->scale);
     const int reserve = NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 32;
     const int64_t lead0 = 64;  // columns of block column 0 that stay on the float32 MFMA (see potrf_lookahead_f32)
-    const bool use_helper = !(NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) && reserve >= 8 && reserve % 8 == 0;
+    // Helper grids (round 3: the reserved compute units join a far chunk once the diagonal-block chain is done) are OFF here: the chain
+    // now runs ahead of the update stream and the bulk solves live on those units -- a persistent helper grid starves both (measured:
+    // chains of 1.3 - 2.8 ms instead of 0.6, Cholesky 54.8 ms).  Debug key 8 = 8: on, behind Tb_k on the bulk stream.
+    const bool use_helper = (NNGP_KNOB(8) & 8) && reserve >= 8 && reserve % 8 == 0;
     const bool early_gp = (NNGP_KNOB(8) & 4) != 0;  // measured: one more CG iteration (6 instead of 5 at N = 32768) -- off
     auto plane_rows = [&](int col, int64_t row) { return sw->planes + (int64_t)col * sw->col_stride + row * ldp; };
     auto width = [&](int64_t col0) { return (n - col0 < nb) ? n - col0 : nb; };
@@ -1120,7 +1128,7 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         // workgroup at a time) and the bulk solve; that many workgroups join the chunk from a stream of their own (debug key 8 = 8:
         // from the bulk stream, behind Tb_k).  Not from the panel stream as in round 3: the chain no longer waits for the chunk.
         if (ph.on) {
-            hipStream_t SH = (NNGP_KNOB(8) & 8) ? SB : (la->aux != nullptr ? la->aux : SB);
+            hipStream_t SH = SB;
             NNGP_HIP_CHECK(hipStreamWaitEvent(SH, la->ev_chunk[ph.step], 0));
             rc = launch_gemm_nt_h3r(a, ld, plane_rows(ph.kl, 0), plane_rows(ph.kl, 0), ldp, sw->col_stride, ph.np, ph.lead, ph.reg, ph.nreg, nb,
                                     ascale, 1.0f, true, sw->counters, reserve, SH, nullptr, 2);

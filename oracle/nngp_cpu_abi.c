@@ -420,12 +420,23 @@ int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
     free(da); free(db); free(sa);
     return 0;
 }
-/* pool scoring: the same keys (counter-based generator) and the same order as the device kernels */
-static uint64_t splitmix64_host(uint64_t seed, uint64_t idx) {
-    uint64_t z = (idx + 1ULL) * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
+/* pool scoring: the same keys and the same order as the device kernels (csrc/posterior.hip).  biased: the reference's draw
+ * jax.random.choice(PRNGKey(seed), m, (count,), replace=False, p = score / sum) (active/ActiveLearner.py:50-53), restated in
+ * nngp-src_amd/jaxrand.py: Threefry-2x32-20 on the counter pair (i, m + i) -> 52 mantissa bits -> Gumbel top-k. */
+static void threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t* px0, uint32_t* px1) {
+    const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    static const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    uint32_t x0 = *px0 + ks[0], x1 = *px1 + ks[1];
+    for (int g = 0; g < 5; ++g) {
+        for (int r = 0; r < 4; ++r) {
+            x0 += x1;
+            x1 = (x1 << rot[g & 1][r]) | (x1 >> (32 - rot[g & 1][r]));
+            x1 ^= x0;
+        }
+        x0 += ks[(g + 1) % 3];
+        x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+    }
+    *px0 = x0; *px1 = x1;
 }
 int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* var, int64_t count, int32_t biased, uint64_t seed,
                      int64_t* indices, void* stream) {
@@ -439,15 +450,20 @@ int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* va
         const double sc = sqrt(fmax(var[i], 0.0)) / mx;
         double k = sc;
         if (biased) {
-            double u = (double)(splitmix64_host(seed, (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
-            if (u < 1.1102230246251565e-16) u = 1.1102230246251565e-16;
+            uint32_t x0 = (uint32_t)i, x1 = (uint32_t)(m + i);
+            threefry2x32_host((uint32_t)(seed >> 32), (uint32_t)seed, &x0, &x1);
+            const uint64_t bits = ((((uint64_t)x0 << 32) | (uint64_t)x1) >> 12) | 0x3FF0000000000000ULL;
+            const double tiny = 2.2250738585072014e-308;
+            double u;
+            memcpy(&u, &bits, sizeof(u));
+            u = fmax(tiny, (u - 1.0) * (1.0 - tiny) + tiny);
             k = (sc > 0.0) ? log(sc) - log(-log(u)) : -INFINITY;
         }
         key[i] = (k == k) ? k : -INFINITY;
     }
     for (int64_t i = 0; i < m; ++i) {
         int64_t r = 0;
-        for (int64_t j = 0; j < m; ++j) r += (key[j] > key[i] || (key[j] == key[i] && j > i)) ? 1 : 0;
+        for (int64_t j = 0; j < m; ++j) r += (key[j] > key[i] || (key[j] == key[i] && (biased ? j < i : j > i))) ? 1 : 0;
         if (r < count) indices[biased ? r : count - 1 - r] = i;
     }
     free(key);
