@@ -199,6 +199,7 @@ def launch_ranks(n_ranks):
         # communicator (a different configuration, named in the line) -- a crash there must not cost the whole measurement
         sys.stderr.write(err[-3000:])
         sys.stderr.write("\nbench.py: child run failed (code %d); second attempt with NNGP_COLLECTIVE=torch\n" % child.returncode)
+        first_rc, first_err = child.returncode, err[-1500:]
         env["NNGP_COLLECTIVE"] = "torch"
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -218,6 +219,7 @@ def launch_ranks(n_ranks):
             if ln.startswith("{") and '"metric"' in ln:
                 d = json.loads(ln)
                 d["launcher_note"] = "first attempt (library-owned RCCL communicator) failed; this line is the NNGP_COLLECTIVE=torch run"
+                d["first_attempt"] = {"returncode": first_rc, "stderr_tail": first_err}  # so that gating sees the failure behind rc 0
                 line = json.dumps(d)
     if child.returncode != 0 or line is None:
         sys.stderr.write(err[-6000:])
@@ -401,7 +403,7 @@ def main():
                         "allgather_GBps_per_rank": round(recv_bytes / 1e9 / (st["allgather"] * 1e-3), 1) if st["allgather"] > 0 else None,
                         "replicated_full_build_ms": None, "replicate_layout_ms_per_step": None,
                         "ranks_seen": ranks_seen, "collective": collective,
-                        "cholesky": ("1-D block-cyclic, one broadcast per 1024-wide block column (%s)" % ("nngp_bcast on a side stream" if comm is not None and os.environ.get("NNGP_BCAST", "native") == "native" else "torch.distributed broadcast")) if dist_chol else "replicated on every rank"}
+                        "cholesky": ("1-D block-cyclic, one broadcast per 1024-wide block column (%s)" % ("nngp_bcast on a side stream" if comm is not None and os.environ.get("NNGP_BCAST", "torch") == "native" else "torch.distributed broadcast")) if dist_chol else "replicated on every rank"}
         if not args.no_compare:
             model.set_train(xd, yd)
             ts = []

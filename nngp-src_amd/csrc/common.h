@@ -35,9 +35,13 @@ void set_error(const char* fmt, ...);
 //      order instead of deferred
 //   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
 //   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
-//   8  round 4, grouped Cholesky: 1 = the round-3 schedule (panel solves on the update stream); 2 = bulk panel solves on the panel
-//      stream itself; 4 = early part of the next group's first diagonal-block update on its own stream; 8 = helper grids behind the bulk solves; 16 = a far chunk's next-column region and its share in one launch
-//   9  round 4, posterior solves: block columns per step of the blocked triangular solves (default 2; 1 = round 3)
+//   8  round 4, grouped Cholesky (set BEFORE the model is created): bit 1 = the schedule with the panel solves off the update stream
+//      (potrf_lookahead_grouped_v4; needs its extra streams); with it: 2 = bulk panel solves on the panel stream itself; 4 = early part
+//      of the next group's first diagonal-block update on its own stream; 8 = helper grids behind the bulk solves; 16 = a far chunk's
+//      next-column region in a launch of its own; 32 = finished diagonal blocks inverted on a side stream under the last block columns
+//   9  round 4, posterior solves: 2 = 2048-wide inverted blocks / two 1024-column panels per step of the blocked solves from np = 8192 on
+//      (measured: posterior -0.5 ms, block inverses +1.1 ms at N = 32768 -- off)
+//  10  block columns from the end where key 8 = 32 issues the inverses; 11  priority of that side stream; 12  print the schedule's stream end times
 #ifdef NNGP_TIMING_KNOBS
 extern std::atomic<int> g_knobs[16];
 #define NNGP_KNOB(i) (nngp::g_knobs[i].load(std::memory_order_relaxed))
@@ -103,12 +107,13 @@ int launch_diag_from_q(const double* q, int64_t n, const ArchDev& arch, double* 
 int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s);
 
 // ---- gemm_f32.hip ----
+// tri: the square B is lower (1) / upper (2) triangular -- every column tile only walks the k range where its rows of B are non-zero
 int launch_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
-                       int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s);
+                       int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s, int tri = 0);
 
 int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
                                int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int batch,
-                               int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s);
+                               int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s, int tri = 0);
 
 // ---- gemm_h3.hip: float32-grade products on the float16 matrix pipe (two float16 planes per operand) ----
 int launch_split_rows(const float* p, int64_t ld, int64_t rows, int64_t k, float scale, char* out, int64_t out_ld,

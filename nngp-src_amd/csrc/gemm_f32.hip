@@ -41,9 +41,9 @@ __device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((c
 //   <1,1>  64x64   small problems: 4x the workgroups, a quarter of the serial MFMA chain per workgroup
 template <int WM, int WN, bool LOWER>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, const float* A, int64_t lda,
-                                                        const float* B, int64_t ldb, int tiles_n, int nk,
+                                                        const float* B, int64_t ldb, int tiles_n, int nk_all,
                                                         float alpha, float beta, int64_t sc, int64_t sa,
-                                                        int64_t sb) {
+                                                        int64_t sb, int tri) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int STAGE_FLOATS = (BM + BN) * BK;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
@@ -67,6 +67,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
     const float* Ab = A + (int64_t)blockIdx.y * sa + (int64_t)bi * BM * lda;
     const float* Bb = B + (int64_t)blockIdx.y * sb + (int64_t)bj * BN * ldb;
 
+    // tri: B is triangular (the inverted diagonal blocks of the blocked solves) -- a column tile's K range shrinks to where its rows
+    // of B are non-zero: 1 = lower (B[c][k] = 0 for k > c): k-tiles [0, hi]; 2 = upper (zero for k < c): k-tiles [lo, nk).  The
+    // skipped terms are exact zeros, so the result is the full product's, bit for bit.
+    int kt_hi = nk_all - 1, kt_lo = 0;
+    if (tri == 1) {
+        const int lim = ((bj + 1) * BN + BK - 1) / BK - 1;
+        kt_hi = lim < kt_hi ? lim : kt_hi;
+    } else if (tri == 2) {
+        kt_lo = (bj * BN) / BK;
+    }
+    const int nk = kt_hi - kt_lo + 1;
     // global -> register staging: 16-byte chunks (4 k), 8 chunks per 128-byte row
     f32x4 ga[BM / 32], gb[BN / 32];
     const int ld_row = tid >> 3, ld_ch = tid & 7;  // + 32 rows per e
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
     // the early columns of L dominate (the factor's columns decay with k); summing the small late-column terms first
     // keeps the float32 partial sums small, which cuts the accumulated rounding error of a K ~ 16k chain by ~20x.
     auto load_tile = [&](int t) {
-        const int64_t k0 = (int64_t)(nk - 1 - t) * BK + ld_ch * 4;
+        const int64_t k0 = (int64_t)(kt_hi - t) * BK + ld_ch * 4;
 #pragma unroll
         for (int e = 0; e < BM / 32; ++e)
             ga[e] = *reinterpret_cast<const f32x4*>(Ab + (int64_t)(ld_row + 32 * e) * lda + k0);
@@ -154,12 +165,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(float* C, int64_t ldc, c
 template <int WM, int WN, bool LOWER>
 int launch_variant(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
                    int64_t n, int64_t k, float alpha, float beta, int batch, int64_t sc, int64_t sa, int64_t sb,
-                   hipStream_t s) {
+                   hipStream_t s, int tri = 0) {
     const int64_t tm = m / (64 * WM), tn = n / (64 * WN);
     const int64_t nb = LOWER ? tm * (tm + 1) / 2 : tm * tn;
     NNGP_REQUIRE(nb < (LOWER ? 16000000LL : 2147483647LL), "gemm_nt_f32: grid too large");
     hipLaunchKernelGGL((k_gemm_nt_f32<WM, WN, LOWER>), dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, s, c, ldc, a,
-                       lda, b, ldb, (int)tn, (int)(k / BK), alpha, beta, sc, sa, sb);
+                       lda, b, ldb, (int)tn, (int)(k / BK), alpha, beta, sc, sa, sb, tri);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -168,7 +179,8 @@ int launch_variant(float* c, int64_t ldc, const float* a, int64_t lda, const flo
 
 int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb,
                                int64_t m, int64_t n, int64_t k, float alpha, float beta, bool lower_only, int batch,
-                               int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s) {
+                               int64_t stride_c, int64_t stride_a, int64_t stride_b, hipStream_t s, int tri) {
+    NNGP_REQUIRE(tri == 0 || (tri >= 1 && tri <= 2 && n == k && !lower_only), "gemm_nt_f32: a triangular B must be square");
     if (m <= 0 || n <= 0 || batch <= 0) return 0;
     NNGP_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % BK == 0 && k > 0,
                  "gemm_nt_f32: m, n must be multiples of 128 and k of 32 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n,
@@ -187,23 +199,23 @@ int launch_gemm_nt_f32_batched(float* c, int64_t ldc, const float* a, int64_t ld
         NNGP_REQUIRE(m == n, "gemm_nt_f32: lower_only needs a square result");
         if (t128 >= 192)
             return launch_variant<2, 2, true>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
-                                              stride_b, s);
+                                              stride_b, s, tri);
         return launch_variant<1, 1, true>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
-                                          stride_b, s);
+                                          stride_b, s, tri);
     }
     if (t128 >= 192)
         return launch_variant<2, 2, false>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
-                                           stride_b, s);
+                                           stride_b, s, tri);
     if (in_place || t128 >= 96)
         return launch_variant<1, 2, false>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
-                                           stride_b, s);
+                                           stride_b, s, tri);
     return launch_variant<1, 1, false>(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, batch, stride_c, stride_a,
-                                       stride_b, s);
+                                       stride_b, s, tri);
 }
 
 int launch_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
-                       int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s) {
-    return launch_gemm_nt_f32_batched(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only, 1, 0, 0, 0, s);
+                       int64_t n, int64_t k, float alpha, float beta, bool lower_only, hipStream_t s, int tri) {
+    return launch_gemm_nt_f32_batched(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only, 1, 0, 0, 0, s, tri);
 }
 
 }  // namespace nngp

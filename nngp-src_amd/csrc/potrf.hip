@@ -614,16 +614,21 @@ int lookahead_create(LookAhead** out) {
         // solves must outrank the update stream: their workgroups take the compute units a trailing-update launch gives back before
         // the next launch's persistent grid settles there.  With two levels there is no side stream.
         const bool three = least - greatest >= 2;
-        const int prio_update = three ? least - 1 : least;
+        const int prio_update = (three && (NNGP_KNOB(8) & 1)) ? least - 1 : least;
         if (hipStreamCreateWithPriority(&la->panel, hipStreamNonBlocking, greatest) != hipSuccess ||
             hipStreamCreateWithPriority(&la->update, hipStreamNonBlocking, prio_update) != hipSuccess) {
             set_error("lookahead_create: hipStreamCreateWithPriority failed");
             delete la;
             return -1;
         }
-        if (hipStreamCreateWithPriority(&la->bulk, hipStreamNonBlocking, greatest) != hipSuccess) la->bulk = nullptr;
-        if (hipStreamCreateWithPriority(&la->aux, hipStreamNonBlocking, greatest) != hipSuccess) la->aux = nullptr;
-        if (!three || hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, least) != hipSuccess) la->side = nullptr;
+        // Every further stream costs: HIP multiplexes streams onto a few hardware queues, and a fifth look-ahead stream with work pending
+        // on it stretched the whole factorisation by a third (measured: 40.7 -> 55 ms at N = 32768; not when profiled).  The streams of
+        // the round-4 schedule only exist when that experiment is switched on.
+        if (!(NNGP_KNOB(8) & 1) || hipStreamCreateWithPriority(&la->bulk, hipStreamNonBlocking, greatest) != hipSuccess) la->bulk = nullptr;
+        if (!(NNGP_KNOB(8) & 1) || !three || hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, NNGP_KNOB(11) == 1 ? prio_update : NNGP_KNOB(11) == 2 ? greatest : least) != hipSuccess) la->side = nullptr;
+        // (the stream of the early diagonal-block product, debug key 8 = 4, only exists when that experiment is on: every further stream
+        // costs -- see the note on the side stream in DESIGN.md)
+        if (!(NNGP_KNOB(8) & 4) || hipStreamCreateWithPriority(&la->aux, hipStreamNonBlocking, greatest) != hipSuccess) la->aux = nullptr;
         la->prio_levels = least - greatest + 1;
     }
     hipEvent_t* all[5] = {&la->ev_in, &la->ev_panel_done, &la->ev_update_done, &la->ev_bulk_done, &la->ev_side_done};
@@ -931,6 +936,13 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
                                       SplitWork* sw, hipStream_t user, int64_t nb, int D, TriInv* ti) {
     la->tu_count = 0;
     hipStream_t SP = la->panel, SU = la->update, SB = (NNGP_KNOB(8) & 2) ? la->panel : la->bulk;
+#ifdef NNGP_TIMING_KNOBS
+    static hipEvent_t dbg_ev[8] = {};
+    const bool dbg = NNGP_KNOB(12) != 0;
+    if (dbg && dbg_ev[0] == nullptr)
+        for (auto& e : dbg_ev) (void)hipEventCreate(&e);
+    if (dbg) (void)hipEventRecord(dbg_ev[0], user);
+#endif
     NNGP_HIP_CHECK(hipEventRecord(la->ev_in, user));
     NNGP_HIP_CHECK(hipStreamWaitEvent(SP, la->ev_in, 0));
     NNGP_HIP_CHECK(hipStreamWaitEvent(SU, la->ev_in, 0));
@@ -1035,9 +1047,9 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         }
         // column gend + i + 1 of the next group in a launch of its own: the chain (G, P of that column) waits for this launch only,
         // not for the chunk's share of the columns beyond -- the diagonal-block chain then runs a whole step ahead of the update
-        // stream and the bulk solve of a block column has the following far chunk to hide under (debug key 8 = 16: one launch)
+        // stream and the bulk solve of a block column has the following far chunk to hide under (debug key 8 = 16 only)
         const int64_t c1 = r0 + (int64_t)(i + 1) * nb;
-        const bool split_c1 = !(NNGP_KNOB(8) & 16) && step >= 0;
+        const bool split_c1 = (NNGP_KNOB(8) & 16) && step >= 0;  // measured: +0.6 ms (one more launch per step) -- off
         if (c1 < n && i + 1 < D) add(c1, c1, width(c1), 0);
         if (split_c1 && nreg > 0) {
             NNGP_TRY(far_launch(reg, nreg, step, false));
@@ -1056,7 +1068,7 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
 
     int rc = 0;
     bool side_used = false;
-    constexpr int kTriInvTail = 7;  // block columns from the end where the finished blocks' inverses are issued
+    const int kTriInvTail = NNGP_KNOB(10) > 0 ? NNGP_KNOB(10) : 7;  // block columns from the end where the finished blocks' inverses are issued
     for (int k = 0; k < nblk && rc == 0; ++k) {
         const int64_t o = (int64_t)k * nb;
         const int64_t nbk = width(o);
@@ -1072,14 +1084,22 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         if (rc != 0) break;
         // The inverted diagonal blocks of the blocked solves (solve.hip, triinv_build): from here on the chain of diagonal-block
         // factorisations bounds the factorisation and most of the chip idles -- the blocks of the block columns behind us are
-        // inverted now, on the lowest-priority stream, instead of after the factorisation (debug key 8 = 32: not here).
-        if (ti != nullptr && la->side != nullptr && !(NNGP_KNOB(8) & 32) && k == nblk - kTriInvTail && ti->bs % nb == 0 && k >= 2) {
+        // inverted now, on the lowest-priority stream, instead of after the factorisation.  Debug key 8 = 32 only: measured, the side work
+        // delays the chain by what it saves after the factorisation (42.1 against 42.3 ms at N = 32768).
+        if (ti != nullptr && la->side != nullptr && (NNGP_KNOB(8) & 32) && k == nblk - kTriInvTail && ti->bs % nb == 0 && k >= 2) {
             const int64_t jdone = ((int64_t)(k - 1) * nb) / ti->bs;  // block columns 0 .. k - 2 are final (P_{k-1} has been waited for by Tc_{k-1})
             if (jdone > 0) {
-                NNGP_HIP_CHECK(hipStreamWaitEvent(la->side, la->ev_tc[k - 1], 0));
-                rc = triinv_build_range(a, ld, dinv, n, *ti, 0, jdone, la->side);
+                hipStream_t SS = NNGP_KNOB(11) == 3 ? la->aux : NNGP_KNOB(11) == 4 ? la->bulk : la->side;
+                NNGP_HIP_CHECK(hipStreamWaitEvent(SS, la->ev_tc[k - 1], 0));
+#ifdef NNGP_TIMING_KNOBS
+                if (dbg) (void)hipEventRecord(dbg_ev[1], SS);
+#endif
+                rc = triinv_build_range(a, ld, dinv, n, *ti, 0, jdone, SS);
                 if (rc != 0) break;
-                NNGP_HIP_CHECK(hipEventRecord(la->ev_side_done, la->side));
+#ifdef NNGP_TIMING_KNOBS
+                if (dbg) (void)hipEventRecord(dbg_ev[2], SS);
+#endif
+                NNGP_HIP_CHECK(hipEventRecord(la->ev_side_done, SS));
                 ti->done_blocks = jdone;
                 side_used = true;
             }
@@ -1215,6 +1235,9 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
     bool dummy = false, dummy2 = false;
     while (rc == 0 && far.active) rc = far_step(-1, &dummy, &dummy2);  // (nothing is left when the loop ran to the last block column)
     if (rc == 0) sw->l_ready = true;
+#ifdef NNGP_TIMING_KNOBS
+    if (dbg) { (void)hipEventRecord(dbg_ev[3], SP); (void)hipEventRecord(dbg_ev[4], SU); (void)hipEventRecord(dbg_ev[5], SB); }
+#endif
     NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, SP));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, SU));
     NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_panel_done, 0));
@@ -1222,6 +1245,17 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
     NNGP_HIP_CHECK(hipEventRecord(la->ev_bulk_done, SB));
     NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_bulk_done, 0));
     if (side_used) NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_side_done, 0));
+#ifdef NNGP_TIMING_KNOBS
+    if (dbg) {
+        (void)hipEventRecord(dbg_ev[6], user);
+        (void)hipEventSynchronize(dbg_ev[6]);
+        float t[7] = {};
+        for (int i = 1; i <= 6; ++i)
+            if (i > 2 || side_used) (void)hipEventElapsedTime(&t[i], dbg_ev[0], dbg_ev[i]);
+        fprintf(stderr, "v4 timing (ms from entry): side %.2f -> %.2f | panel end %.2f  update end %.2f  bulk end %.2f | user resumes %.2f\n", t[1], t[2], t[3],
+                t[4], t[5], t[6]);
+    }
+#endif
     return rc;  // (the aux stream's last product was waited for by the panel stream)
 }
 
@@ -1247,7 +1281,9 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
     // grouped form: deep-K far updates (debug key 2 = 10 + D overrides the group size; D = 1: the round-2 form below)
     const int group = (NNGP_KNOB(2) >= 11 && NNGP_KNOB(2) <= 26) ? NNGP_KNOB(2) - 10 : (NNGP_KNOB(2) >= 31 && NNGP_KNOB(2) <= 46) ? NNGP_KNOB(2) - 30 : kLookAheadGroup;
     if (h3 && group > 1 && nb == 1024 && (NNGP_KNOB(2) == 0 || NNGP_KNOB(2) >= 11) && NNGP_KNOB(3) == 0 && ld % 4 == 0) {
-        if (la->bulk != nullptr && !(NNGP_KNOB(8) & 1))
+        // (round 4's schedule with the panel solves off the update stream -- measured equal at N = 32768, slower at the other sizes,
+        // see the note above it -- runs on request only: debug key 8 bit 1, set before the model is created)
+        if (la->bulk != nullptr && (NNGP_KNOB(8) & 1))
             return potrf_lookahead_grouped_v4(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group, ti);
         return potrf_lookahead_grouped(a, n, ld, dinv, clamped, pivot_floor, la, sw, user, nb, group);
     }

@@ -272,10 +272,12 @@ int launch_transpose_blocks_f32(const float* src, float* dst, int64_t bs, int64_
     return 0;
 }
 
-// Round 4: 2048-wide inverted blocks from np = 8192 on (the sizes whose posterior solves run on the float16 pipe): the blocked solves take
-// half as many steps, each with K = 2048 per pass over the right-hand sides, and the CG's blocked TRSVs half as many launches.
+// Round 4 built 2048-wide inverted blocks (debug key 9 = 2, from np = 8192 on): the blocked solves then take half as many steps,
+// each with two 1024-column panels (K = 2048) per pass over the right-hand sides, and the CG's blocked TRSVs half as many launches.
+// Measured at N = 32768, M = 1024: the three solves 19.9 -> 19.2 ms (a step's diagonal GEMM is a full 2048^2 product: 95 us against
+// 2 x 30), posterior -0.5 ms, but the inverses cost the factorisation stage +1.1 ms -- 1024 stays.
 int64_t triinv_block(int64_t np) {
-    int64_t bs = NNGP_KNOB(6) >= 128 ? (int64_t)NNGP_KNOB(6) : (np >= 8192 && NNGP_KNOB(9) != 1) ? 2048 : 1024;  // debug key 6: block size experiment; 9 = 1: round 3
+    int64_t bs = NNGP_KNOB(6) >= 128 ? (int64_t)NNGP_KNOB(6) : (np >= 8192 && NNGP_KNOB(9) == 2) ? 2048 : 1024;  // debug key 6: block size experiment
     return np < bs ? np : bs;
 }
 
@@ -312,6 +314,11 @@ int triinv_build(const float* l, int64_t ld, const float* dinv, int64_t np, TriI
     return triinv_build_range(l, ld, dinv, np, ti, j0, (np + ti.bs - 1) / ti.bs, s);
 }
 
+// The inverted blocks are triangular (X_J = L_JJ^-1 lower, T_J = L_JJ^-T upper): the multiplication by them skips the k tiles where a
+// column tile's rows of the block are zero -- 45 % of a 1024-block's product (round 4; debug key 9 = 4: the full product).
+#define kTriLower (NNGP_KNOB(9) == 4 ? 0 : 1)
+#define kTriUpper (NNGP_KNOB(9) == 4 ? 0 : 2)
+
 // B[m, np] <- B L^-T with the inverted bs-blocks: per block column J one GEMM with X_J = L_JJ^-1 (out of place into
 // `tmp`, [m, bs]) and one trailing GEMM -- 3 launches per block instead of the ~16 of the 128-wide recursion.
 int trsm_rlt_blocks_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ld, const TriInv& ti, int64_t np,
@@ -319,7 +326,7 @@ int trsm_rlt_blocks_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_
     const int64_t bs = ti.bs;
     for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
         const int64_t sz = (np - o < bs) ? np - o : bs;
-        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s, kTriLower));
         NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
                                         hipMemcpyDeviceToDevice, s));
         const int64_t rest = np - o - sz;
@@ -338,7 +345,7 @@ int trsm_rut_blocks_f32(float* b, int64_t ldb, int64_t m, const float* lt, int64
     for (int64_t j = nblk - 1; j >= 0; --j) {
         const int64_t o = j * bs;
         const int64_t sz = (np - o < bs) ? np - o : bs;
-        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s, kTriUpper));
         NNGP_HIP_CHECK(hipMemcpy2DAsync(b + o, sizeof(float) * ldb, tmp, sizeof(float) * sz, sizeof(float) * sz, m,
                                         hipMemcpyDeviceToDevice, s));
         if (o > 0)
@@ -385,7 +392,7 @@ int trsm_rlt_blocks_h3(float* b, int64_t ldb, int64_t m, const float* l, int64_t
     for (int64_t o = 0, j = 0; o < np; o += bs, ++j) {
         const int64_t sz = (np - o < bs) ? np - o : bs;
         const int64_t rest = np - o - sz;
-        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.xinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s, kTriLower));
         if (rest > 0 && sz == bs && h3_worth(m, rest)) {
             NNGP_TRY(launch_split_rows_rowscale(tmp, sz, m, sz, b + o, ldb, sw.planes_b, ldp, sw.row_inv, s, sw.col_stride));
             // rows o + sz .. of L, columns [o, o + sz): block columns o / kc .. of the factor's split copy, rows at their global index
@@ -409,7 +416,7 @@ int trsm_rut_blocks_h3(float* b, int64_t ldb, int64_t m, const float* lt, int64_
     for (int64_t j = nblk - 1; j >= 0; --j) {
         const int64_t o = j * bs;
         const int64_t sz = (np - o < bs) ? np - o : bs;
-        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s));
+        NNGP_TRY(launch_gemm_nt_f32(tmp, sz, b + o, ldb, ti.tinv + j * bs * bs, bs, m, sz, sz, 1.0f, 0.0f, false, s, kTriUpper));
         // lt == nullptr: no float32 copy of L^T exists (it is only built for the float32 path) -- every update, also the
         // few-tile ones and the tail block, goes through the split copy: +0.07 ms per small step, -1.8 ms of transposition
         if (o > 0 && (lt == nullptr || (sz == bs && h3_worth(m, o)))) {

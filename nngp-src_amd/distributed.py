@@ -258,9 +258,12 @@ def distributed_factor(model, group=None, nb: int = None, comm: "NativeComm" = N
     owned = [j for j in range(ncols) if j % world == r]
     width = lambda j: min(w, np_ - j * w)
     stages = [torch.empty(((np_ * w) + w * 128,), dtype=torch.float32, device=a32.device) for _ in range(2)] if world > 1 else None
-    # with the library's own communicator the panels travel by nngp_bcast (NNGP_BCAST=torch: torch.distributed's broadcast)
+    # The panels travel by torch.distributed's broadcast.  NNGP_BCAST=native: by nngp_bcast on a side stream of the library's own
+    # communicator -- opt-in until one run on two or more GPUs has checked that path against the single-GPU factor (it has only
+    # ever run as a one-rank self-broadcast: no multi-GPU box was available to rounds 1-4; tests/test_gpu_distributed.py holds the
+    # two-GPU test that will)
     import os
-    native = _NativeBcast(comm) if (comm is not None and world > 1 and os.environ.get("NNGP_BCAST", "native") == "native") else None
+    native = _NativeBcast(comm) if (comm is not None and world > 1 and os.environ.get("NNGP_BCAST", "torch") == "native") else None
 
     def views(k):
         o, wk = k * w, width(k)

@@ -16,7 +16,7 @@ runs it (``jax_enable_x64``):
 Pinned by the Random123 known-answer vectors of Threefry-2x32-20 (the vectors jax's own ``random_test.py`` checks;
 ``tests/test_host.py``).  NOT pinned against jax itself -- the surrounding steps follow the release's source as
 restated above, and ``log`` is the platform's: two keys closer than one ulp could swap.  The same draw runs on the
-device (``nngp_pool_select``, csrc/posterior.hip) and in the host build of the ABI (oracle/nngp_cpu_abi.c).
+device (``nngp_pool_select``, csrc/posterior.hip) and in the host build of the ABI (the checker's C restatement of include/nngp_hip.h).
 """
 from __future__ import annotations
 

@@ -101,8 +101,10 @@ def test_host_build_carries_the_line_encoder(golden_dir):
 
 def test_pool_select_host_build_against_numpy():
     """nngp_pool_select (active/ActiveLearner.py:43-55): score = std / max(mean); the top `count` scores in ascending order are
-    np.argsort(score)[-count:], and the score-proportional draw without replacement is a Gumbel top-k on the counter-based
-    generator of synth.py -- re-stated here in NumPy."""
+    np.argsort(score)[-count:], and the score-proportional draw without replacement is the reference's
+    jax.random.choice(PRNGKey(seed), m, (count,), replace=False, p=score / sum(score)) -- restated in NumPy in
+    nngp_src_amd/jaxrand.py (Threefry-2x32-20 -> 52-bit uniforms -> Gumbel top-k); the host build must make the same draw."""
+    from nngp_src_amd import jaxrand
     rng = np.random.default_rng(5)
     m, count = 700, 150
     mean = rng.uniform(0.5, 19.0, size=(m, 1))
@@ -111,14 +113,12 @@ def test_pool_select_host_build_against_numpy():
     score = np.sqrt(var) / mean.max(0)
     got = c_abi.pool_select(mean, var, count)
     np.testing.assert_array_equal(got, np.argsort(score, kind="stable")[-count:])
-    u = np.maximum(synth.uniform01(10, np.arange(m, dtype=np.uint64)), 2.0 ** -53)
-    with np.errstate(divide="ignore"):
-        key = np.where(score > 0, np.log(score) - np.log(-np.log(u)), -np.inf)
-    want = np.argsort(-key, kind="stable")[:count]
-    np.testing.assert_array_equal(c_abi.pool_select(mean, var, count, biased=True, seed=10), want)
-    # the draw follows the scores: the selected half carries more score mass than the rest
+    for seed in (10, 3, (7 << 32) | 5):
+        want = jaxrand.choice_without_replacement(seed, m, count, score / score.sum())
+        np.testing.assert_array_equal(c_abi.pool_select(mean, var, count, biased=True, seed=seed), want)
+    # zero scores are never drawn while positive ones are left; the draw follows the scores
     sel = c_abi.pool_select(mean, var, m // 2, biased=True, seed=3)
-    assert len(set(sel.tolist())) == m // 2 and score[sel].mean() > 1.2 * np.delete(score, sel).mean()
+    assert len(set(sel.tolist())) == m // 2 and score[sel].min() > 0.0 and score[sel].mean() > 1.2 * np.delete(score, sel).mean()
     assert c_abi.lib().nngp_pool_select(None, 5, 1, None, 2, 0, 0, None, None) != 0
 
 

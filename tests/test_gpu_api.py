@@ -153,11 +153,45 @@ def test_active_learning_loop(golden_dir):
     m_ref, c_ref = post.predict(Xpool, "nngp", True)
     score = np.sqrt(np.diag(c_ref)) / np.max(m_ref, 0)
     want = set(np.argsort(score)[-150:].tolist())
-    learner2 = ActiveLearner(budget=150, active_iters=0)
+    learner2 = ActiveLearner(budget=150, active_iters=0, biased_sample=False)
     with contextlib.redirect_stdout(io.StringIO()):
         pf = learner2.train(kernel_fn, Xtr, Ytr)
     got = set(learner2.active_test(pf, Xpool).tolist())
     assert len(got ^ want) <= 2  # identical up to ties at the selection boundary
+
+
+def test_active_train_driver_with_the_reference_default_draw(golden_dir):
+    """active/active_train.py:21-51 end to end on forest fixture rows with the reference's defaults (--biased_sample True): the
+    20 / 60 / 20 split, three fits (the later two extend the factor), and the pool draw of every round equal to the restated
+    jax.random.choice(PRNGKey(10), ...) on the oracle's posterior of the same training set (identical up to scores that differ
+    in the last digits: the device posterior against the float64 oracle)."""
+    from nngp_src_amd import active_train, jaxrand
+    from nngp_src_amd.active import ActiveLearner
+    g = np.load(os.path.join(golden_dir, "forest_n1000_m200.npz"))
+    X = np.vstack([g["X_train"], g["X_test"]])
+    Y = np.vstack([g["Y_train"].reshape(-1, 1), g["Y_test"].reshape(-1, 1)])
+    args = active_train.parse_args(["--budget", "120", "--active_iters", "2"])
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        learner = active_train.main(args, data=(X, Y, None))
+    out = buf.getvalue()
+    n = X.shape[0]
+    assert "number of query: %d" % n in out and out.count("Test MSE Loss:") == 3
+    assert "# Initial Training samples: %d" % int(n * 0.2) in out and "Active Iteration 1: Selection 120" in out
+    assert "# Training samples: %d" % (int(n * 0.2) + 240) in out
+    assert learner.biased_sample is True and learner.history[-1] < learner.history[0] * 1.5
+    # the first round's draw against the oracle
+    Xtr, Ytr, _, Xpool, Ypool, _, _, _, _ = active_train.split_20_60_20(X, Y)
+    post = o.Posterior(np.asarray(Xtr), np.asarray(Ytr), o.make_arch(1), diag_reg=1e-3)
+    m_ref, c_ref = post.predict(np.asarray(Xpool), "nngp", True)
+    score = np.sqrt(np.diag(c_ref)) / np.max(m_ref, 0)
+    want = jaxrand.choice_without_replacement(10, score.shape[0], 120, score / score.sum())
+    learner2 = ActiveLearner(budget=120, active_iters=0)
+    _, _, kernel_fn = stax.serial(stax.Dense(512), stax.Relu(), stax.Dense(1))
+    with contextlib.redirect_stdout(io.StringIO()):
+        pf = learner2.train(kernel_fn, np.asarray(Xtr), np.asarray(Ytr))
+    got = learner2.active_test(pf, np.asarray(Xpool))
+    assert got.shape == (120,) and len(set(got.tolist()) ^ set(want.tolist())) <= 2
+    assert np.mean(got == want) > 0.9  # draw ORDER too, wherever the scores agree to the last digits
 
 
 @pytest.mark.parametrize("n0,b,ncap", [(1500, 700, 2200), (4200, 1000, 6000), (4096, 128, 4224)])

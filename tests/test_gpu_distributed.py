@@ -121,6 +121,86 @@ def test_native_rccl_communicator_single_rank():
     comm.close()
 
 
+def _worker_rccl(rank, world, port, n, d, out_dir, bcast):
+    """One rank per GPU, backend nccl (= RCCL): the library-owned communicator end to end."""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["NNGP_BCAST"] = bcast
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from nngp_src_amd import distributed, synth, _lib
+        from nngp_src_amd.model import GPModel
+        comm = distributed.NativeComm()
+        assert comm.world == world and comm.rank == rank
+        # nngp_allgather_rows in place: every rank fills its own row block, all of them end up with every block
+        rows = 5 * world + 3
+        chunk = distributed.row_chunk(rows, world)
+        k = torch.full((chunk * world, 16), -1.0, dtype=torch.float64, device="cuda")
+        r0, r1 = distributed.row_partition(rows, world, rank)
+        k[r0:r1] = float(rank + 1)
+        comm.allgather_rows(k, rows)
+        torch.cuda.synchronize()
+        for q in range(world):
+            q0, q1 = distributed.row_partition(rows, world, q)
+            assert torch.all(k[q0:q1] == float(q + 1)), (rank, q)
+        # nngp_bcast from every root
+        for root in range(world):
+            v = torch.full((1000,), float(rank), dtype=torch.float32, device="cuda")
+            comm.bcast(v, root)
+            torch.cuda.synchronize()
+            assert torch.all(v == float(root))
+        # the fit: row-sharded build, in-place all-gather, block-cyclic factorisation with broadcast panels
+        x, y = synth.synthetic_queries(n, d, seed=0)
+        xt, _ = synth.synthetic_queries(64, d, seed=1)
+        n_cap = distributed.row_chunk(n, world) * world
+        model = GPModel(n_cap, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3)
+        distributed.sharded_fit(model, x, y, comm=comm)
+        info = model.info()
+        assert info["clamped_pivots"] == 0 and info["rel_residual"] < 1e-10, info
+        mean, var = model.predict(xt, cov="diag")
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean, var=var, alpha=model.alpha().cpu().numpy())
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bcast", ["torch", "native"])
+def test_library_owned_rccl_communicator_on_two_gpus(tmp_path, bcast):
+    """SURVEY.md 8e on real links, as soon as a box with two or more GPUs runs this suite (rounds 1-4 only ever had one: skipped
+    there): the library's OWN RCCL communicator (csrc/collective.cpp: dlopen'd librccl, unique id carried by torch.distributed) at
+    world = 2 -- nngp_allgather_rows in place, nngp_bcast from every root, and distributed.sharded_fit (row-sharded kernel build,
+    all-gather, 1-D block-cyclic factorisation with one broadcast per block column) against the single-GPU fit: alpha to 1e-9,
+    no clamped pivot.  `native`: the panels through nngp_bcast on a side stream (NNGP_BCAST=native, opt-in until this test has
+    passed once on hardware); `torch`: through torch.distributed's broadcast (the default)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: the library-owned RCCL communicator cannot put two ranks on one device")
+    n, d = 4096 + 300, 32
+    sys.path.insert(0, ROOT)
+    from nngp_src_amd import synth
+    from nngp_src_amd.model import GPModel
+    mp.spawn(_worker_rccl, args=(2, _free_port(), n, d, str(tmp_path), bcast), nprocs=2, join=True)
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(64, d, seed=1)
+    torch.cuda.set_device(0)
+    ref = GPModel(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    m0, v0 = ref.predict(xt, cov="diag")
+    a0 = ref.alpha().cpu().numpy()
+    for r in range(2):
+        g = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.linalg.norm(g["alpha"] - a0) / np.linalg.norm(a0) < 1e-9
+        assert np.linalg.norm(g["mean"] - m0) / np.linalg.norm(m0) < 1e-9
+        np.testing.assert_allclose(g["var"], v0, rtol=1e-6)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "rccl_two_gpu_%s.txt" % bcast), "w") as f:
+            f.write("library-owned RCCL communicator at world = 2 (NNGP_BCAST=%s): all-gather, broadcast, sharded fit == single-GPU fit\n" % bcast)
+
+
 def _worker2d(rank, world, port, pr, pc, n, d, nb, out_dir):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:

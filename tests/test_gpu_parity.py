@@ -347,21 +347,20 @@ def test_grouped_cholesky_matches_the_one_column_form(n):
 
 @pytest.mark.parametrize("n", [9300, 13440])
 def test_cholesky_schedule_with_the_panel_solves_off_the_update_stream(n):
-    """Round 4's schedule of the grouped Cholesky (panel solves on the panel / bulk streams, trailing updates alone on the update
-    stream, far chunks in up to three launches, finished diagonal blocks inverted on a side stream under the last block columns)
-    against round 3's (debug key 8 = 1: everything but the diagonal-block factorisations in line on the update stream).  Every tile
-    sees the same arithmetic in the same order: the factors, alpha and the posterior of a block of queries must agree BIT FOR BIT
-    -- any read-modify-write race between the five streams would show here.  Also with the far chunks in one launch (key 8 = 16)
-    and the inverses after the factorisation (32).  The variant with the early part of the next group's first diagonal-block
-    update on its own stream (key 8 = 4; off: it costs a CG iteration at N = 32768) differs by float32 rounding in those
-    diagonal blocks only; alpha, the float64 CG answer, agrees to 1e-9."""
+    """Round 4's experimental schedule of the grouped Cholesky (debug key 8 bit 1, knobs build only: panel solves on the panel / bulk
+    streams, trailing updates alone on the update stream -- measured no faster than round 3's, see potrf.hip) against the product's
+    schedule.  Every tile sees the same arithmetic in the same order: the factors, alpha and the posterior of a block of queries
+    must agree BIT FOR BIT -- any read-modify-write race between the streams would show here.  Also with a far chunk's next-column
+    region in its own launch (16) and the finished diagonal blocks inverted on a side stream under the last block columns (32).
+    The variant with the early part of the next group's first diagonal-block update on its own stream (4; it costs a CG iteration
+    at N = 32768) differs by float32 rounding in those diagonal blocks only; alpha, the float64 CG answer, agrees to 1e-9."""
     from nngp_src_amd import _lib
     x, y = synth.synthetic_queries(n, 48, seed=41)
     xt, _ = synth.synthetic_queries(300, 48, seed=42)
     lib = _lib.load(knobs=True)
     res = {}
-    for key8 in (1, 0, 0, 16, 32, 4):
-        lib.nngp_debug_set(8, key8)
+    for key8 in (0, 1, 1, 17, 33, 5):
+        lib.nngp_debug_set(8, key8)  # read when the model (its streams) is created
         try:
             mdl = GPModel(n, 48, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
             a32, _ = mdl.factor_buffers()
@@ -370,13 +369,13 @@ def test_cholesky_schedule_with_the_panel_solves_off_the_update_stream(n):
             mdl.close()
         finally:
             lib.nngp_debug_set(8, 0)
-    (i3, a3, l3, m3, v3) = res[1][0]
-    for key8 in (0, 16, 32):
+    (i3, a3, l3, m3, v3) = res[0][0]
+    for key8 in (1, 17, 33):
         for (i4, a4, l4, m4, v4) in res[key8]:
             assert i4["clamped_pivots"] == 0
             assert torch.equal(l3, l4) and np.array_equal(a3, a4), key8
             assert np.array_equal(m3, m4) and np.array_equal(v3, v4), key8  # the inverted blocks too
-    (i0, a0, l0, _, _) = res[4][0]
+    (i0, a0, l0, _, _) = res[5][0]
     assert i0["clamped_pivots"] == 0 and i0["rel_residual"] < 1e-9 and abs(i0["refine_iters"] - i3["refine_iters"]) <= 1
     assert np.linalg.norm(a0 - a3) <= 1e-9 * np.linalg.norm(a3)
     assert (l0 - l3).abs().max().item() <= 2e-3 * l3.abs().max().item()
@@ -499,18 +498,29 @@ def test_trsm_right_lower_transposed():
     assert resid < 5e-4, resid
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("n,rows", [(9300, 1024), (10800, 600), (12288, 256), (8192, 1000)])
-def test_blocked_solves_of_the_posterior_against_scipy(n, rows):
-    """The posterior's blocked triangular solves (round 4: 2048-column steps -- two 1024-column panels per step of the
-    split-float16 updates -- from N = 8192 on; reference: the cho_solve inside predict_fn, train.py:157-158) against
-    scipy.linalg.solve_triangular on the model's own float32 factor, at sizes that are not multiples of the step (9300 -> 9344 =
-    4 x 2048 + 1024 + 128; 10800 -> 10880 = 5 x 2048 + 640), row counts that are not multiples of the tile, and one block below
-    the float16 path's row threshold.  Gate: the residual  X L^T - B  against the scale |X| |L|^T of its terms (what a
-    backward-stable float32 substitution leaves is ~ n eps of that; the blocked form multiplies by inverted diagonal blocks, so a
-    few times more), and the solution against the float64 solve within that residual's reach."""
+def test_blocked_solves_of_the_posterior_against_scipy(n, rows, wide):
+    """The posterior's blocked triangular solves (reference: the cho_solve inside predict_fn, train.py:157-158) through
+    nngp_model_apply_factor against scipy.linalg.solve_triangular on the model's own float32 factor, at sizes that are not multiples
+    of the step (9300 -> 9344 = 9 x 1024 + 128 = 4 x 2048 + 1152; 10800 -> 10880 = 5 x 2048 + 640), row counts that are not
+    multiples of the tile, and blocks below the float16 path's thresholds.  `wide`: round 4's 2048-column steps (two 1024-column
+    panels per split-float16 update; debug key 9 = 2, knobs build -- measured and not adopted, solve.hip).  Gate: the residual
+    X L^T - B  against the scale |X| |L|^T of its terms (what a backward-stable float32 substitution leaves is ~ n eps of that;
+    the blocked form multiplies by inverted diagonal blocks, so a few times more), and the solution against the float64 solve
+    within that residual's reach."""
     import scipy.linalg as sla
+    from nngp_src_amd import _lib
     x, y = synth.synthetic_queries(n, 24, seed=51)
-    model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    if wide:
+        _lib.load(knobs=True).nngp_debug_set(9, 2)  # read when the model's workspaces are sized
+    try:
+        model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3, knobs=wide).fit(x, y)
+    finally:
+        if wide:
+            _lib.load(knobs=True).nngp_debug_set(9, 0)
+    if wide:
+        _lib.load(knobs=True).nngp_debug_set(9, 2)
     a32, _ = model.factor_buffers()
     L = torch.tril(a32[:n, :n]).double().cpu().numpy()
     rng = np.random.default_rng(n + rows)
@@ -528,6 +538,30 @@ def test_blocked_solves_of_the_posterior_against_scipy(n, rows):
     scale2 = np.abs(Y) @ np.abs(L).T + (np.abs(Z) @ np.abs(L)) @ np.abs(L).T
     res2 = np.abs(Y @ L.T - B)
     assert (res2 / scale2).max() < 2e-5, (res2 / scale2).max()
+    model.close()
+    if wide:
+        _lib.load(knobs=True).nngp_debug_set(9, 0)
+
+
+def test_triangular_inverse_blocks_skip_their_zero_tiles_bit_for_bit():
+    """Round 4: the blocked solves multiply by the inverted diagonal blocks with a float32 GEMM that walks, per column tile, only the
+    k tiles where the (triangular) block is non-zero.  The skipped terms are exact zeros: the solve must return the bits of the
+    full product (debug key 9 = 4, knobs build)."""
+    from nngp_src_amd import _lib
+    n, rows = 5000, 384
+    x, y = synth.synthetic_queries(n, 24, seed=61)
+    lib = _lib.load(knobs=True)
+    model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+    B = torch.randn((rows, n), device=G.dev(), dtype=torch.float32)
+    out = {}
+    for key9 in (0, 4):
+        lib.nngp_debug_set(9, key9)
+        try:
+            out[key9] = (model.apply_factor(B.clone()).clone(), model.apply_factor(B.clone(), both_halves=True).clone())
+        finally:
+            lib.nngp_debug_set(9, 0)
+    assert torch.equal(out[0][0], out[4][0]) and torch.equal(out[0][1], out[4][1])
+    assert torch.isfinite(out[0][1]).all()
     model.close()
 
 

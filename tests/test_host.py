@@ -267,3 +267,58 @@ def test_native_encoder_is_bit_identical(golden_dir):
         nat.encode_lines(["orders,cust@o_id,1,0"])
     with pytest.raises(_lib.NngpError, match="unknown column"):
         single.encode_lines(["Z,1,0@5"], with_card=True)
+
+
+def test_threefry_known_answers_and_the_restated_jax_draw():
+    """jaxrand.py restates jax.random.choice(PRNGKey(10), n, (k,), replace=False, p) of the pinned jax 0.3.23
+    (reference active/ActiveLearner.py:50-53).  Pins: the Random123 known-answer vectors of Threefry-2x32-20 (the three
+    vectors jax's own random_test.py checks); jax.random.uniform(PRNGKey(0)) = 0.41845703 in float32 -- the widely quoted first
+    draw, which exercises the key layout, the counter layout and the mantissa fill of the same pipeline at 32 bits; then the
+    statistics of the 64-bit draw.  Unpinned against jax itself (not installable here)."""
+    from nngp_src_amd import jaxrand as J
+    u32 = lambda v: np.array([v], dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        for key, ctr, want in [((0, 0), (0, 0), (0x6b200159, 0x99ba4efe)),
+                               ((0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x1cb996fc, 0xbb002be7)),
+                               ((0x13198a2e, 0x03707344), (0x243f6a88, 0x85a308d3), (0xc4923a9c, 0x483df7a0))]:
+            y0, y1 = J.threefry2x32((np.uint32(key[0]), np.uint32(key[1])), u32(ctr[0]), u32(ctr[1]))
+            assert (int(y0[0]), int(y1[0])) == want
+        # float32 scalar draw of jax: one block on the padded counter pair (0, 0), first word, 23 mantissa bits
+        y0, _ = J.threefry2x32(J.prng_key(0), u32(0), u32(0))
+    f = ((y0 >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+    assert abs(float(f[0]) - 0.41845703) < 1e-7
+    assert J.prng_key(10) == (0, 10) and J.prng_key((3 << 32) | 9) == (3, 9)
+    u = J.uniform64(J.prng_key(10), 200000)
+    assert 0.0 < u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 3e-3 and abs(np.mean(u < 0.1) - 0.1) < 3e-3
+    # the draw: distinct indices, deterministic, proportional to p (first draw frequencies over many seeds)
+    p = np.array([0.5, 0.25, 0.125, 0.125])
+    first = np.array([J.choice_without_replacement(seed, 4, 2, p)[0] for seed in range(4000)])
+    freq = np.bincount(first, minlength=4) / 4000.0
+    assert np.abs(freq - p).max() < 0.03
+    a = J.choice_without_replacement(10, 1000, 100, np.full(1000, 1e-3))
+    assert len(set(a.tolist())) == 100 and np.array_equal(a, J.choice_without_replacement(10, 1000, 100, np.full(1000, 1e-3)))
+    # zero-probability entries are never drawn
+    pz = np.array([0.0, 0.5, 0.0, 0.5])
+    assert set(J.choice_without_replacement(10, 4, 2, pz).tolist()) == {1, 3}
+
+
+def test_active_train_cli_flags_and_split():
+    """active_train.py mirrors the reference driver's flags (active/active_train.py:54-107) -- including `--biased_sample` parsed with
+    type=bool, i.e. any non-empty value is True -- and its 20 / 60 / 20 split of the seed-10 shuffle (:26-27)."""
+    from nngp_src_amd import active_train
+    from nngp_src_amd.util import train_test_val_split
+    a = active_train.parse_args([])
+    assert a.biased_sample is True and a.budget == 1000 and a.active_iters == 3 and a.kernel_type == "nngp" and a.chunk_size == 10
+    assert active_train.parse_args(["--biased_sample", "False"]).biased_sample is True   # the reference's type=bool
+    assert active_train.parse_args(["--top_k"]).biased_sample is False
+    b = active_train.parse_args(["--budget", "50", "--active_iters", "2", "--kernel_type", "ntk", "--relations", "a,b"])
+    assert (b.budget, b.active_iters, b.kernel_type, b.join_query) == (50, 2, "ntk", True)
+    X = np.arange(1000, dtype=np.float64).reshape(500, 2)
+    Y = np.arange(500, dtype=np.float64).reshape(500, 1)
+    out = active_train.split_20_60_20(X, Y)
+    ref = train_test_val_split(X, Y, train_frac=0.2, test_frac=0.6)
+    assert out[0].shape[0] == 100 and out[3].shape[0] == 300 and out[6].shape[0] == 100
+    for g, r in zip(out, ref):
+        assert (g is None and r is None) or np.array_equal(np.asarray(g), np.asarray(r))
+    from nngp_src_amd.active import ActiveLearner
+    assert ActiveLearner().biased_sample is True  # the reference's default
