@@ -8,6 +8,8 @@
 #include <cmath>
 #include <new>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace nngp {
@@ -128,6 +130,15 @@ struct nngp_model {
     // float64 pipe and the fit stays there.
     bool i8_checked = false, i8_distrusted = false, i8_used_now = false;
     double i8_floor_ratio = -1.0;
+    // ... and on EVERY later level-1 predict of the fit (round 4: a later batch may sit closer to training points, its variances orders
+    // of magnitude smaller): the estimate comes from statistics the variance's own row-dot pass collects, its one word travels to the host
+    // without a wait and is looked at when the NEXT predict starts -- a batch that trips it sends the fit to the float64 pipe from then on
+    // (the batch itself is not redone: only the first predict of a fit waits for its own estimate).
+    unsigned long long* i8_guard = nullptr;       // device word
+    unsigned long long* i8_guard_host = nullptr;  // pinned
+    hipEvent_t ev_guard = nullptr;
+    bool i8_guard_pending = false;
+    bool i8_want_fine = false;  // sticky: see i8s_planes_policy
     bool i8_suspended = false;   // prepare_serving: the explicit inverse is refined against residuals of the float64 pipe itself  // prepare_serving: the explicit inverse is refined against float64 residuals proper
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
@@ -178,7 +189,9 @@ struct nngp_model {
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
         dev_free(ainv64);
         dev_free(rows.p); dev_free(rows.q); dev_free(rows.rho); dev_free(rows.coef); dev_free(rows.tol); dev_free(rows.delta);
-        dev_free(rows.var); dev_free(rows.state); dev_free(rows.live);
+        dev_free(rows.var); dev_free(rows.state); dev_free(rows.live); dev_free(rows.zstat); dev_free(i8_guard);
+        if (i8_guard_host) (void)hipHostFree(i8_guard_host);
+        if (ev_guard) (void)hipEventDestroy(ev_guard);
         if (rows.host) (void)hipHostFree(rows.host);
     }
 };
@@ -284,9 +297,10 @@ int ensure_refine_capacity(nngp_model* m, int64_t mp) {
     if (mp > m->rows.cap) {
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         RowsPcg& w = m->rows;
-        dev_free(w.rho); dev_free(w.coef); dev_free(w.tol); dev_free(w.delta); dev_free(w.var); dev_free(w.state);
+        dev_free(w.rho); dev_free(w.coef); dev_free(w.tol); dev_free(w.delta); dev_free(w.var); dev_free(w.state); dev_free(w.zstat);
         NNGP_TRY(dev_alloc(&w.rho, mp)); NNGP_TRY(dev_alloc(&w.coef, mp)); NNGP_TRY(dev_alloc(&w.tol, mp));
         NNGP_TRY(dev_alloc(&w.delta, mp)); NNGP_TRY(dev_alloc(&w.var, mp)); NNGP_TRY(dev_alloc(&w.state, mp));
+        NNGP_TRY(dev_alloc(&w.zstat, 2 * mp));
         if (w.live == nullptr) {
             NNGP_TRY(dev_alloc(&w.live, 6));
             NNGP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&w.host), 6 * sizeof(int32_t), hipHostMallocDefault));
@@ -351,7 +365,12 @@ constexpr int kI8FinePlanes = 7, kI8FineCut = 6;
 
 // FINE pays later than COARSE (28 against 15 products): from N = 4096 and four 128-row tiles of right-hand sides on.  Debug key 5 = 57: off.
 bool use_i8s_fine(const nngp_model* m, int64_t mp) { return use_i8s(m, mp) && m->np >= 4096 && mp >= 512 && NNGP_KNOB(5) != 57; }
-int i8s_planes_policy(const nngp_model* m) { return (m->get == NNGP_GET_NTK || m->var_refine >= 2) && NNGP_KNOB(5) != 57 ? kI8FinePlanes : 5; }
+// (i8_want_fine: a predict of this model has needed a FINE product before -- a full covariance at level 1 is promoted to level 2, a weak
+// fit's rows continue with later residuals -- so the planes are cut seven deep from the start instead of being thrown away, reallocated
+// and cut again in the middle of a predict)
+int i8s_planes_policy(const nngp_model* m) {
+    return (m->get == NNGP_GET_NTK || m->var_refine >= 2 || m->i8_want_fine) && NNGP_KNOB(5) != 57 ? kI8FinePlanes : 5;
+}
 
 template <typename T>
 static bool soft_alloc(T** p, int64_t count) {  // false (and no sticky error) when the device has no room
@@ -499,6 +518,7 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
 int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s, bool first_residual) {
     const int64_t np = m->np;
     const bool coarse = first_residual;
+    if (!coarse && use_i8s_fine(m, mp)) m->i8_want_fine = true;
     if (coarse ? use_i8s(m, mp) : use_i8s_fine(m, mp)) {
         const int rc = ensure_i8s(m, mp, m->i8.k, coarse ? i8s_planes_policy(m) : kI8FinePlanes);
         if (rc == 0) {
@@ -828,6 +848,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     m->a32_built = false;
     m->i8.k.ready = false;
     m->i8_checked = m->i8_distrusted = false;
+    m->i8_guard_pending = false;
     if (a.sym) {  // whole matrix in one build: the float32 factorisation input falls out of the same epilogue
         if (m->get == NNGP_GET_NNGP) { a.nngp32 = m->a32; a.diag_add_nngp32 = m->reg; }
         else { a.ntk32 = m->a32; a.diag_add_ntk32 = m->reg; }
@@ -978,6 +999,7 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     m->serving_ready = false;
     m->i8.k.ready = false;
     m->i8_checked = m->i8_distrusted = false;
+    m->i8_guard_pending = false;
     // 2. kernel rows [n0, n1) against all n1 rows, their mirror image, and the new padding
     BuildArgs a{};
     a.x1 = m->x; a.x2 = m->x; a.q1 = m->q; a.q2 = m->q;
@@ -1335,6 +1357,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     // traffic) are cut on the solve stream while this stream runs the first two blocked solves, whose launches leave most of the
     // chip's bandwidth and, between them, its compute units idle.  (debug key 5 = 53: in stream order where they are first needed)
     if (cov_mode != NNGP_COV_NONE && m->var_refine >= 1 && use_i8s(m, mp) && !(m->serving_ready && !is_ntk) && NNGP_KNOB(5) != 53) {
+        if (cov_mode == NNGP_COV_FULL && use_i8s_fine(m, mp)) m->i8_want_fine = true;  // a full covariance runs at level >= 2: later residuals
         const int rc_i8 = ensure_i8s(m, mp, m->i8.k, i8s_planes_policy(m));
         if (rc_i8 != 0 && rc_i8 != 1) return rc_i8;
         if (rc_i8 == 0 && !m->i8.k.ready) {
@@ -1345,6 +1368,13 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, m->solve_stream));
             m->i8_k_pending = true;
         }
+    }
+    if (m->i8_guard_pending && hipEventQuery(m->ev_guard) == hipSuccess) {  // the previous level-1 batch's estimate has arrived
+        double ratio = 0.0;
+        memcpy(&ratio, m->i8_guard_host, sizeof(double));
+        m->i8_guard_pending = false;
+        if (ratio > m->i8_floor_ratio) m->i8_floor_ratio = ratio;
+        if (!(ratio <= kI8FloorThr)) m->i8_distrusted = true;  // float64 pipe from this predict on
     }
     int check_kind = 0;
     bool i8_check_pending = false;
@@ -1437,18 +1467,30 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             NNGP_TRY(solve_rows(0, true));
             z_valid = true;
             NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
-            NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s));
+            NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s,
+                                       m->i8_used_now ? m->rows.zstat : nullptr));
             NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
             NNGP_TRY(apply_forward_f32(m, mp, s));
             NNGP_TRY(launch_row_sqsum_f32(m->b32, np, mt, np, var_or_cov, var_or_cov, s));
             check_kind = 4;  // like 1, and r64 already holds the residual of z64
-            if (m->i8_used_now && !m->i8_checked) {  // first int8 residual of this fit: what may the dropped digit pairs have cost?
+            if (m->i8_used_now) {  // an int8 residual: what may the dropped digit pairs have cost THIS batch's variances?
                 I8Plan pl;
                 NNGP_TRY(i8s_plan(m->i8.ns_z, m->i8.ns_k, m->i8.cut, &pl));
-                NNGP_HIP_CHECK(hipMemsetAsync(m->rows.live + 2, 0, sizeof(unsigned long long), s));
-                NNGP_TRY(launch_i8s_floor_ratio(m->z64, np, mt, np, var_or_cov, pl, m->i8.ns_z, m->i8.ns_k, m->i8.k.scale + m->np_cap,
-                                                reinterpret_cast<unsigned long long*>(m->rows.live + 2), s));
-                i8_check_pending = true;
+                if (m->i8_guard == nullptr) {
+                    NNGP_TRY(dev_alloc(&m->i8_guard, 1));
+                    NNGP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->i8_guard_host), sizeof(unsigned long long), hipHostMallocDefault));
+                    NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_guard, hipEventDisableTiming));
+                }
+                NNGP_HIP_CHECK(hipMemsetAsync(m->i8_guard, 0, sizeof(unsigned long long), s));
+                NNGP_TRY(launch_i8s_floor_ratio_rows(m->rows.zstat, mt, var_or_cov, pl, m->i8.ns_z, m->i8.ns_k, m->i8.k.scale + m->np_cap,
+                                                     m->i8_guard, s));
+                if (!m->i8_checked) {
+                    i8_check_pending = true;   // first predict of the fit: waits for its own estimate (below)
+                } else {
+                    NNGP_HIP_CHECK(hipMemcpyAsync(m->i8_guard_host, m->i8_guard, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                    NNGP_HIP_CHECK(hipEventRecord(m->ev_guard, s));
+                    m->i8_guard_pending = true;  // looked at when the next predict starts
+                }
             }
             return launch_rows_prepare(m->rows.delta, m->tt_diag, var_or_cov, nullptr, 0, kFlagThr, mt, m->rows.tol,
                                        m->rows.live + 1, s);
@@ -1555,13 +1597,14 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     if (i8_check_pending) {
         // (the host has just waited for the alpha solve: this read-back waits for the covariance kernels enqueued before it, once
         // per fit -- later predicts on the fit stay asynchronous)
-        NNGP_HIP_CHECK(hipMemcpyAsync(m->rows.host + 2, m->rows.live + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+        NNGP_HIP_CHECK(hipMemcpyAsync(m->i8_guard_host, m->i8_guard, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         NNGP_HIP_CHECK(hipStreamSynchronize(s));
-        memcpy(&m->i8_floor_ratio, m->rows.host + 2, sizeof(double));
+        memcpy(&m->i8_floor_ratio, m->i8_guard_host, sizeof(double));
         m->i8_checked = true;
         const double thr = NNGP_KNOB(5) == 56 ? 0.0 : kI8FloorThr;  // key 5 = 56: distrust whatever the estimate says (test)
         if (!(m->i8_floor_ratio <= thr)) {
             m->i8_distrusted = true;  // use_i8s is false from here on: the covariance again, on the float64 pipe
+            m->i8_used_now = false;
             NNGP_TRY(cov_part());
         }
     }
@@ -1664,6 +1707,50 @@ int nngp_gemm_nt_f32(float* c, int64_t ldc, const float* a, int64_t lda, const f
     return launch_gemm_nt_f32(c, ldc, a, lda, b, ldb, m, n, k, alpha, beta, lower_only != 0, (hipStream_t)stream);
 }
 
+// Split workspace of nngp_gemm_nt_h3, kept between calls (round 4; until then every call allocated, synchronised and freed -- a host
+// wait and a hipMalloc per block column inside the distributed factorisation's collective loop): one grow-only buffer per stream, a
+// few streams at most; work on one stream is ordered, so the buffer is reused without waiting.
+namespace {
+struct H3Scratch {
+    hipStream_t stream = nullptr;
+    char* p = nullptr;
+    size_t bytes = 0;
+    bool used = false;
+};
+std::mutex g_h3_scratch_mutex;
+H3Scratch g_h3_scratch[4];
+
+int h3_scratch_get(hipStream_t s, size_t bytes, char** out) {
+    std::lock_guard<std::mutex> lock(g_h3_scratch_mutex);
+    H3Scratch* e = nullptr;
+    for (auto& c : g_h3_scratch)
+        if (c.used && c.stream == s) e = &c;
+    if (e == nullptr)
+        for (auto& c : g_h3_scratch)
+            if (!c.used && e == nullptr) e = &c;
+    if (e == nullptr) {  // every slot belongs to another stream: take the first one over once its work is through
+        e = &g_h3_scratch[0];
+        NNGP_HIP_CHECK(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->p);
+        *e = H3Scratch();
+    }
+    if (e->bytes < bytes) {
+        if (e->p != nullptr) {
+            NNGP_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(e->p);
+            e->p = nullptr;
+            e->bytes = 0;
+        }
+        NNGP_HIP_CHECK(hipMalloc((void**)&e->p, bytes));
+        e->bytes = bytes;
+    }
+    e->used = true;
+    e->stream = s;
+    *out = e->p;
+    return 0;
+}
+}  // namespace
+
 int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t n,
                     int64_t k, float alpha, float beta, float scale, int32_t lower_only, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1671,18 +1758,16 @@ int nngp_gemm_nt_h3(float* c, int64_t ldc, const float* a, int64_t lda, const fl
     NNGP_REQUIRE(m > 0 && n > 0 && k > 0 && k % 32 == 0, "gemm_nt_h3: k must be a multiple of 32");
     const int64_t mp = round_up(m, 256), np = round_up(n, 256), ldp = 4 * k;
     char* pa = nullptr;
-    NNGP_HIP_CHECK(hipMalloc((void**)&pa, (size_t)((mp + np) * ldp + 64)));
-    NNGP_HIP_CHECK(hipMemsetAsync(pa, 0, (size_t)((mp + np) * ldp + 64), s));
+    NNGP_TRY(h3_scratch_get(s, (size_t)((mp + np) * ldp + 64), &pa));
     char* pb = pa + mp * ldp;
     int* counters = reinterpret_cast<int*>(pb + np * ldp);
-    int rc = launch_split_rows(a, lda, m, k, scale, pa, ldp, s);
-    if (rc == 0) rc = launch_split_rows(b, ldb, n, k, scale, pb, ldp, s);
-    if (rc == 0)
-        rc = launch_gemm_nt_h3(c, ldc, pa, pb, ldp, m, n, k, alpha / (scale * scale), beta, lower_only != 0, 0, counters,
-                               NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 0, s);
-    (void)hipStreamSynchronize(s);
-    (void)hipFree(pa);
-    return rc;
+    // the padding rows' products are never stored, but they are read: zero (finite) operands; the work counters start at zero
+    if (mp > m) NNGP_HIP_CHECK(hipMemsetAsync(pa + m * ldp, 0, (size_t)((mp - m) * ldp), s));
+    NNGP_HIP_CHECK(hipMemsetAsync(pb + n * ldp, 0, (size_t)((np - n) * ldp + 64), s));
+    NNGP_TRY(launch_split_rows(a, lda, m, k, scale, pa, ldp, s));
+    NNGP_TRY(launch_split_rows(b, ldb, n, k, scale, pb, ldp, s));
+    return launch_gemm_nt_h3(c, ldc, pa, pb, ldp, m, n, k, alpha / (scale * scale), beta, lower_only != 0, 0, counters,
+                             NNGP_KNOB(4) > 0 ? NNGP_KNOB(4) : 0, s);
 }
 
 int nngp_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,

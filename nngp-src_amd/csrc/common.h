@@ -256,6 +256,9 @@ int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double
 int launch_i8s_scale_sqsum(const double* scale, int64_t n, double* out, hipStream_t s);
 int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t cols, const double* var, const I8Plan& pl, int nsa, int nsb,
                            const double* sk2, unsigned long long* out, hipStream_t s);
+// the same estimate from per-row statistics of z (|z|_2^2, max |z|: launch_rowdot_f64's zstat) instead of a pass over z
+int launch_i8s_floor_ratio_rows(const double* zstat, int64_t rows, const double* var, const I8Plan& pl, int nsa, int nsb, const double* sk2,
+                                unsigned long long* out, hipStream_t s);
 int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t cols, int ns, const double* scale_in, double* scale_out,
                           int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s);  // scale_in NULL: scale by the row maxima
 int launch_gemm_nt_i8s(int32_t* partial, int64_t ldc, int64_t slab, const int8_t* a, int64_t lda, int64_t sa, const int8_t* b,
@@ -338,7 +341,7 @@ int launch_f32_to_f64_mat(const float* src, int64_t lds, double* dst, int64_t ld
 int launch_axpby_mat(double* r, double a, const double* k, double b, int64_t ld, int64_t rows, int64_t cols,
                      hipStream_t s);
 int launch_rowdot_f64(const double* z, const double* k, double kscale, const double* r, int64_t ld, int64_t rows,
-                      int64_t cols, const double* base, double sign, double* out, hipStream_t s);
+                      int64_t cols, const double* base, double sign, double* out, hipStream_t s, double* zstat = nullptr);  // zstat: [2 rows] |z|^2, max |z|
 int launch_copy_mat_f64(const double* src, int64_t lds, double* dst, int64_t m, hipStream_t s);
 int launch_skinny_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,
                          const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta, hipStream_t s);
@@ -354,6 +357,7 @@ struct RowsPcg {
     double* tol = nullptr;    // [cap] stopping threshold on the per-step decrease of e^T A e
     double* delta = nullptr;  // [cap] first-order term z . r of the fixed sweeps
     double* var = nullptr;    // [cap] variance estimate of the fixed sweeps (full-covariance mode)
+    double* zstat = nullptr;  // [2 cap] |z_row|_2^2 and max |z_row| of the level-1 variance's rows (guard of the int8 residual)
     int32_t* state = nullptr; // [cap] >= 0: consecutive small steps; -1: finished
     int32_t* live = nullptr;  // [6] rows still iterating; rows flagged by k_rows_prepare; [2..5]: two doubles, the sweep estimates
     int32_t* host = nullptr;  // pinned [6], same layout

@@ -475,6 +475,17 @@ __global__ __launch_bounds__(256) void k_i8s_floor_ratio(const double* __restric
     }
 }
 
+// the same from the rows' statistics (zstat[2 r] = |z_r|_2^2, zstat[2 r + 1] = max |z_r|): one thread per row
+__global__ __launch_bounds__(256) void k_i8s_floor_ratio_rows(const double* __restrict__ zstat, int64_t rows, const double* __restrict__ var,
+                                                              double coef, const double* __restrict__ sk2, unsigned long long* out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const double est = sqrt(zstat[2 * r]) * coef * i8s_scale_of(zstat[2 * r + 1]) * sqrt(sk2[0]);
+    const double v = var[r];
+    const double ratio = v > 0.0 ? est / v : (est > 0.0 ? 1.0e300 : 0.0);
+    atomicMax(out, (unsigned long long)__double_as_longlong(ratio));
+}
+
 }  // namespace
 
 int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double* scale, hipStream_t s) {
@@ -523,6 +534,23 @@ int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t co
     for (int ia = 0; ia < nsa; ++ia) dropped += (cut + 1 - ia >= 0 && cut + 1 - ia < nsb) ? 1 : 0;
     const double coef = 5404.7 * sqrt((double)dropped) * pow(256.0, -(double)(cut + 3));  // 2^12.4 = 5404.7
     hipLaunchKernelGGL(k_i8s_floor_ratio, dim3((unsigned)rows), dim3(256), 0, s, z, ld, cols, var, coef, sk2, out);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static double i8s_floor_coef(const I8Plan& pl, int nsa, int nsb) {
+    int cut = -1;
+    for (int p = 0; p < pl.npairs; ++p) cut = pl.pa[p] + pl.pb[p] > cut ? pl.pa[p] + pl.pb[p] : cut;
+    int dropped = 2;  // pairs on the first dropped diagonal (+ 2 for the two operands' own truncation at their last plane)
+    for (int ia = 0; ia < nsa; ++ia) dropped += (cut + 1 - ia >= 0 && cut + 1 - ia < nsb) ? 1 : 0;
+    return 5404.7 * sqrt((double)dropped) * pow(256.0, -(double)(cut + 3));  // 2^12.4 = 5404.7
+}
+
+int launch_i8s_floor_ratio_rows(const double* zstat, int64_t rows, const double* var, const I8Plan& pl, int nsa, int nsb, const double* sk2,
+                                unsigned long long* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_i8s_floor_ratio_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, zstat, rows, var,
+                       i8s_floor_coef(pl, nsa, nsb), sk2, out);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -117,23 +117,45 @@ __global__ __launch_bounds__(256) void k_axpby_mat(double* __restrict__ r, doubl
 }
 
 // out[i] = base[i] + sign * sum_j z[i][j] * (kscale * k[i][j] + r[i][j])   (k, r or base may be NULL)
+template <bool STAT>
 __global__ __launch_bounds__(256) void k_rowdot_f64(const double* __restrict__ z, const double* __restrict__ k,
                                                     double kscale, const double* __restrict__ r, int64_t ld,
                                                     int64_t cols, const double* __restrict__ base, double sign,
-                                                    double* __restrict__ out) {
-    __shared__ double red[4];
+                                                    double* __restrict__ out, double* __restrict__ zstat) {
+    // STAT: also zstat[2 row] = |z_row|_2^2 and zstat[2 row + 1] = max |z_row| (the int8 residual's guard reads them: one pass over z less)
+    __shared__ double red[12];
     const int64_t row = blockIdx.x;
-    double s = 0.0;
+    double s = 0.0, s2 = 0.0, mx = 0.0;
     for (int64_t j = threadIdx.x; j < cols; j += 256) {
         double g = 0.0;
         if (k) g = kscale * k[row * ld + j];
         if (r) g += r[row * ld + j];
-        s = fma(z[row * ld + j], g, s);
+        const double zv = z[row * ld + j];
+        s = fma(zv, g, s);
+        if (STAT) {
+            s2 = fma(zv, zv, s2);
+            mx = fmax(mx, fabs(zv));
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        if (STAT) {
+            s2 += __shfl_down(s2, off);
+            mx = fmax(mx, __shfl_down(mx, off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s;
+        if (STAT) { red[4 + (threadIdx.x >> 6)] = s2; red[8 + (threadIdx.x >> 6)] = mx; }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) out[row] = (base ? base[row] : 0.0) + sign * (red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        out[row] = (base ? base[row] : 0.0) + sign * (red[0] + red[1] + red[2] + red[3]);
+        if (STAT) {
+            zstat[2 * row] = (red[4] + red[5]) + (red[6] + red[7]);
+            zstat[2 * row + 1] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+        }
+    }
 }
 
 // ---- per-row preconditioned CG on [rows, cols] blocks: every row is an independent right-hand side of the same SPD ----
@@ -524,9 +546,12 @@ int launch_axpby_mat(double* r, double a, const double* k, double b, int64_t ld,
 }
 
 int launch_rowdot_f64(const double* z, const double* k, double kscale, const double* r, int64_t ld, int64_t rows,
-                      int64_t cols, const double* base, double sign, double* out, hipStream_t s) {
+                      int64_t cols, const double* base, double sign, double* out, hipStream_t s, double* zstat) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_rowdot_f64, dim3((unsigned)rows), dim3(256), 0, s, z, k, kscale, r, ld, cols, base, sign, out);
+    if (zstat != nullptr)
+        hipLaunchKernelGGL((k_rowdot_f64<true>), dim3((unsigned)rows), dim3(256), 0, s, z, k, kscale, r, ld, cols, base, sign, out, zstat);
+    else
+        hipLaunchKernelGGL((k_rowdot_f64<false>), dim3((unsigned)rows), dim3(256), 0, s, z, k, kscale, r, ld, cols, base, sign, out, zstat);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -325,7 +325,10 @@ class Dist2DGP:
                 # as in the single-GPU solves); block column 0 -- the kernel's dominant, one-signed columns -- stays float32
                 # (accumulator truncation of the float16 pipe on same-sign sums: potrf.hip)
                 h3 = getattr(ops, "gemm_nt_h3", None)
-                if h3 is not None and k > 0 and nb % 32 == 0 and ((mr + 255) // 256) * ((mc + 255) // 256) >= self.h3_min_tiles:
+                # (h3_scale assumes |L_ij| <= sqrt(max A_ii); after a clamped pivot entries can exceed that and the float16 planes would
+                # overflow to inf: from then on this rank's updates stay float32, so that the factor is finite and `clamped` can report it)
+                if (h3 is not None and k > 0 and self.clamped == 0 and nb % 32 == 0
+                        and ((mr + 255) // 256) * ((mc + 255) // 256) >= self.h3_min_tiles):
                     h3(self.a32[i0 * nb:, j0 * nb:], prow, pcol, -1.0, 1.0, self.h3_scale)
                 else:
                     ops.gemm_nt(self.a32[i0 * nb:, j0 * nb:], prow, pcol, -1.0, 1.0)
