@@ -425,13 +425,25 @@ def main():
 
     traffic, traffic_src, k_traffic, r_traffic = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg_name)
+    traffic_note = None
     if os.path.exists(tpath):  # HBM bytes of the Cholesky kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
         _pm = json.load(open(tpath))
+        # the counters are only quoted while the kernel sources they were taken with are unchanged (scripts/pmc_traffic.py records
+        # their hashes): a stale file would silently describe kernels that no longer run
+        import hashlib
+        _csrc = os.path.join(ROOT, "nngp-src_amd", "csrc")
+        _sha = _pm.get("sources_sha16")
+        _changed = sorted(f for f, h in (_sha or {}).items()
+                          if not os.path.exists(os.path.join(_csrc, f)) or hashlib.sha256(open(os.path.join(_csrc, f), "rb").read()).hexdigest()[:16] != h)
+        if _sha is None or _changed:
+            traffic_note = ("profiles/pmc_traffic_%s.json %s: traffic not reported" % (cfg_name, "carries no source fingerprint" if _sha is None
+                            else "predates a change of " + ", ".join(_changed)))
+            _pm = {}
         traffic = _pm.get("cholesky_bytes")
         _k = _pm.get("kernels", {}).get("k_gemm_nt_h3v2<true>") or _pm.get("kernels", {}).get("k_gemm_nt_h3<true>")
         if _k and _k.get("calls"):
             k_traffic = (_k["fetch_bytes"] + _k["write_bytes"]) / _k["calls"]
-        traffic_src = "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
+        traffic_src = traffic_note or "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
         _r = _pm.get("kernels", {}).get("k_gemm_nt_i8s")
         r_traffic = (_r["fetch_bytes"] + _r["write_bytes"]) / _r["calls"] if _r and _r.get("calls") else None
     if rank == 0:
@@ -503,7 +515,7 @@ def main():
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(k_tflops, 3), "peak": round(PEAK_F16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s",
                 "frac": round(k_tflops / (PEAK_F16_MFMA_TFLOPS / 3), 4),
-                "traffic": k_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_h3v2<true>, per launch") if k_traffic else None,
+                "traffic": k_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_h3v2<true>, per launch") if k_traffic else traffic_note,
                 "traffic_over_algorithmic": round(k_traffic / (ktimer["bytes"] / ktimer["launches"]), 3) if k_traffic else None,
                 "kernel": "k_gemm_nt_h3v2<LOWER=true> (split-float16 updates of the grouped look-ahead Cholesky: K = 1024 inside a group "
                           "of 4 block columns, K = 4096 beyond it)",
@@ -533,7 +545,7 @@ def main():
                 # algorithmic bytes per launch: the digit planes of both operands read once + the int32 plane products written once
                 "algorithmic_bytes_per_launch": round((5.0 * (n_pad + m_pad) * n_pad + 4.0 * 5 * m_pad * n_pad * max(1, -(-n_pad // 16384)))
                                                       * (rtimer["flops"] / rtimer["launches"]) / (2.0 * m_pad * n_pad * n_pad), 1),
-                "traffic": r_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_i8s, per launch") if r_traffic else None,
+                "traffic": r_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_i8s, per launch") if r_traffic else traffic_note,
                 "float64_equivalent_tflops": round(rtimer["flops"] / (rtimer["ms"] * 1e-3) / 1e12, 1),
                 "float64_mfma_peak": 78.6,
                 "note": "the float64 matrix pipe peaks at 78.6 TF/s (the kernel this replaced ran the same product at 68); the chip holds "

@@ -542,6 +542,9 @@ bool use_split_solves(const nngp_model* m, int64_t mp) {
 
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
 int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    // While the deferred alpha CG runs on its own stream (from the int8 residual's gate on), the solves' persistent update grids
+    // leave it some compute units (debug key 13 = n: n units; default 0 = none -- see DESIGN_NOTES R4)
+    m->split.solve_reserve = (m->gate_recorded && NNGP_KNOB(13) > 0) ? NNGP_KNOB(13) : 0;
     if (NNGP_KNOB(7) == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
         return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->ld, m->dinv, m->np, s);
     if (use_split_solves(m, mp))
@@ -786,6 +789,8 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         rc = dev_alloc(&m->split.planes, ncols * m->split.col_stride);
         if (rc == 0) rc = dev_alloc(&m->split.counters, 16);
         if (rc == 0 && hipMemset(m->split.counters, 0, 16 * sizeof(int)) != hipSuccess) rc = -1;
+        // the transposed split copy (operand of the posterior's "B L^-1" solves): the factorisation's panel solves write it as they go
+        if (rc == 0 && !soft_alloc(&m->split.planes_t, ncols * m->split.col_stride)) m->split.planes_t = nullptr;  // (no room: built lazily, or float32 path)
         if (rc == 0) rc = dev_alloc(&m->split.ldiag, 2 * kLookAheadNb * kLookAheadNb * 4);
         if (rc == 0) rc = dev_alloc(&m->split.dfrag, 2 * kLookAheadNb * 128);
     }
@@ -1374,7 +1379,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
         memcpy(&ratio, m->i8_guard_host, sizeof(double));
         m->i8_guard_pending = false;
         if (ratio > m->i8_floor_ratio) m->i8_floor_ratio = ratio;
-        if (!(ratio <= kI8FloorThr)) m->i8_distrusted = true;  // float64 pipe from this predict on
+        if (!(ratio <= (NNGP_KNOB(5) == 56 ? 0.0 : kI8FloorThr))) m->i8_distrusted = true;  // float64 pipe from this predict on (key 5 = 56: test)
     }
     int check_kind = 0;
     bool i8_check_pending = false;

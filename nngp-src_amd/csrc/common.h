@@ -144,12 +144,16 @@ int trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, 
                  hipStream_t s);
 
 // ---- trsm_panel.hip: b [m, w] <- b L^-T in one launch (w <= 1024), optionally with the rows' float16 split copy ----
+// planes_t != NULL: also the rows' transposed split copy (SplitWork::planes_t; tstride = its block-row stride, row0 / col0 = the global
+// row of b's first row / global column of the panel's first column)
 int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t w,
-                          char* planes, int64_t ldp, float scale, hipStream_t s);
+                          char* planes, int64_t ldp, float scale, hipStream_t s, char* planes_t = nullptr, int64_t tstride = 0,
+                          int64_t row0 = 0, int64_t col0 = 0);
 int launch_split_diag_frag(const float* a, int64_t ld, int64_t w, float scale, char* out, const float* dinv, float* dfrag,
                            hipStream_t s);
 int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, int64_t w, char* planes,
-                         int64_t ldp, float scale, hipStream_t s);
+                         int64_t ldp, float scale, hipStream_t s, char* planes_t = nullptr, int64_t tstride = 0, int64_t row0 = 0,
+                         int64_t col0 = 0);
 
 
 struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one per model
@@ -171,6 +175,7 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
                                // 1024 columns of a solve step, col_stride bytes apart (the split-float16 kernel walks the panels of both
                                // operands with ONE stride, and the factor's is col_stride)
     int b_panels = 1;          // panels planes_b has room for
+    int solve_reserve = 0;     // compute units the blocked solves' update launches leave free (api.hip sets it while the alpha CG runs beside them)
     float* row_inv = nullptr;  // [mb_cap] per-row 1/scale of planes_b
     int64_t mb_cap = 0;
 };

@@ -752,6 +752,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
     auto plane_rows = [&](int col, int64_t row) { return sw->planes + (int64_t)col * sw->col_stride + row * ldp; };
     auto width = [&](int64_t col0) { return (n - col0 < nb) ? n - col0 : nb; };
     FarWork far;
+    bool wrote_t = true;  // every panel solve also left the transposed split copy
 
     // One launch per chunk: up to three regions of the pending group's far update -- rows [row0, n) x cols [col0, col0 + w), lower
     // trapezoid (col <= row + shift relative to the region's origin) -- with all panels of the group in one pass over C; the
@@ -850,11 +851,16 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
         float* below = akk + nbk * ld;           // panel rows below the diagonal block: [m, nbk]
         float* c = below + nbk;                  // trailing matrix: [m, m]
         char* pk_rows = plane_rows(k, o + nbk);
+        // (round 4: the same launch also leaves the rows' TRANSPOSED split copy -- the operand of the posterior's "B L^-1" solves -- so
+        // that no pass over the finished factor has to write it beside the first solve of a predict; debug key 9 = 8: not here)
+        char* pt = (sw->planes_t != nullptr && nb == sw->k_cap && NNGP_KNOB(9) != 8) ? sw->planes_t : nullptr;
+        wrote_t = wrote_t && pt != nullptr;
         if (k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr) {
             rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, la->update);
-            if (rc == 0) rc = launch_trsm_panel_h3(below, ld, m, sw->ldiag, sw->dfrag, nbk, pk_rows, ldp, sw->scale, la->update);
+            if (rc == 0)
+                rc = launch_trsm_panel_h3(below, ld, m, sw->ldiag, sw->dfrag, nbk, pk_rows, ldp, sw->scale, la->update, pt, sw->col_stride, o + nbk, o);
         } else {
-            rc = launch_trsm_panel_f32(below, ld, m, akk, ld, dk, nbk, pk_rows, ldp, sw->scale, la->update);
+            rc = launch_trsm_panel_f32(below, ld, m, akk, ld, dk, nbk, pk_rows, ldp, sw->scale, la->update, pt, sw->col_stride, o + nbk, o);
         }
         if (rc != 0) break;
         if (k + 1 < gend) {
@@ -908,6 +914,7 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
     }
     while (rc == 0 && far.active) rc = far_chunk(-1);  // (nothing is left when the loop ran to the last block column)
     if (rc == 0) sw->l_ready = true;
+    if (rc == 0 && wrote_t && sw->planes_t != nullptr) sw->lt_ready = true;
     NNGP_HIP_CHECK(hipEventRecord(la->ev_panel_done, la->panel));
     NNGP_HIP_CHECK(hipEventRecord(la->ev_update_done, la->update));
     NNGP_HIP_CHECK(hipStreamWaitEvent(user, la->ev_panel_done, 0));

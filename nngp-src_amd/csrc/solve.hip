@@ -372,11 +372,11 @@ static int h3_step_update(float* c, int64_t ldc, int64_t m, int64_t n, int64_t s
     const float alpha = -1.0f / sw.scale;
     if (sz % kc == 0)  // equal panels: one pass over C, the latest panel first
         return launch_gemm_nt_h3x(c, ldc, sw.planes_b + (int64_t)(np - 1) * sw.col_stride, wrows + (int64_t)(np - 1) * sw.col_stride, ldp,
-                                  sw.col_stride, np, 0, m, n, kc, alpha, 1.0f, false, 0, sw.counters, 0, s, sw.row_inv);
+                                  sw.col_stride, np, 0, m, n, kc, alpha, 1.0f, false, 0, sw.counters, sw.solve_reserve, s, sw.row_inv);
     for (int p = np - 1; p >= 0; --p) {  // a short last panel (tail of the matrix): one launch per panel
         const int64_t kp = (p == np - 1) ? sz - (int64_t)p * kc : kc;
         NNGP_TRY(launch_gemm_nt_h3(c, ldc, sw.planes_b + (int64_t)p * sw.col_stride, wrows + (int64_t)p * sw.col_stride, ldp, m, n, kp, alpha,
-                                   1.0f, false, 0, sw.counters, 0, s, sw.row_inv));
+                                   1.0f, false, 0, sw.counters, sw.solve_reserve, s, sw.row_inv));
     }
     return 0;
 }

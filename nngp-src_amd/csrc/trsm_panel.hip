@@ -36,9 +36,38 @@ __device__ __forceinline__ int stage_off(int row, int ch) { return row * PBK + (
 // 128-column block over the k16 half g of every staged 32-k tile, so each SIMD's matrix pipe is fed by two independent
 // accumulation chains and one wave's LDS latency hides behind the other's MFMAs (one wave per SIMD measured 125-160 us per
 // workgroup against 70 us of MFMA issue time); the two partial sums meet in LDS when the block is done.
+// planes_t (optional): the rows' TRANSPOSED split copy as well -- element (global row i, global column c) of the solved panel goes to
+// planes_t + (i / 1024) * tstride + c * ldp, k = i % 1024: the operand of the posterior's "B L^-1" solves (SplitWork::planes_t), which
+// a separate pass over the finished factor used to write (k_split_lower_t: 2 x 2.1 GB at N = 32768, beside the posterior's first
+// solve).  A workgroup's 32 rows are one 32-k block of 128 columns' rows: one 128-byte line per column and 128-column block.
+struct TPlanes {
+    char* base;        // SplitWork::planes_t (NULL: not written)
+    int64_t tstride;   // bytes between block rows (SplitWork::col_stride)
+    int64_t row0, col0;  // global row of the launch's first row, global column of the panel's first column
+};
+
+__device__ __forceinline__ void write_planes_t(const TPlanes& tp, int64_t ldp, float scale, const float* blk, int blk_stride, int64_t grow0,
+                                               int64_t gcol0, int tid) {
+    // blk: the 32 x 128 block of solved rows in LDS (row stride blk_stride floats); thread -> (column c, group of 8 rows)
+    const int c = tid & 127, part = tid >> 7;
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = blk[(8 * part + e) * blk_stride + c] * scale;
+        const _Float16 h = (_Float16)a;
+        hi[e] = h;
+        lo[e] = (_Float16)(a - (float)h);
+    }
+    const int64_t jrow = grow0 >> 10;
+    const int kb = (int)((grow0 & 1023) >> 5);
+    char* dst = tp.base + jrow * tp.tstride + (gcol0 + c) * ldp + (int64_t)kb * 128 + part * 16;
+    *reinterpret_cast<h8*>(dst) = hi;
+    *reinterpret_cast<h8*>(dst + 64) = lo;
+}
+
 __global__ __launch_bounds__(512) void k_trsm_panel_f32(float* __restrict__ b, int64_t ldb, const float* __restrict__ l,
                                                         int64_t ldl, const float* __restrict__ dinv, int w,
-                                                        char* __restrict__ planes, int64_t ldp, float scale) {
+                                                        char* __restrict__ planes, int64_t ldp, float scale, TPlanes tp) {
     __shared__ __attribute__((aligned(16))) float Xs[PR * PXS];
     __shared__ __attribute__((aligned(16))) float Ls[128 * PBK];  // staged L / dinv tile; partial sums of group 1 between phases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,6 +187,7 @@ __global__ __launch_bounds__(512) void k_trsm_panel_f32(float* __restrict__ b, i
                 *reinterpret_cast<h8*>(pd + 64) = lo;
             }
         }
+        if (tp.base != nullptr) write_planes_t(tp, ldp, scale, Xs + 128 * j, PXS, tp.row0 + row0, tp.col0 + 128 * j, tid);
     }
 }
 
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(256) void k_split_diag_frag(const float* __restrict
 
 __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, int64_t ldb, const char* __restrict__ lsplit,
                                                        const float* __restrict__ dinv, int w, char* __restrict__ planes,
-                                                       int64_t ldp, float scale) {
+                                                       int64_t ldp, float scale, TPlanes tp) {
     __shared__ __attribute__((aligned(16))) char Xp[PR * HXS];     // solved blocks, split rows: [row][k / 32][32 hi | 32 lo]
     __shared__ __attribute__((aligned(16))) float Tf[PR * TFS];    // current block in float32: B_j, then T, then X_j
     __shared__ __attribute__((aligned(16))) float Lf[PR * TFS];    // partial sums of wave group 1, laid out like Tf (lanes along a row:
@@ -394,6 +424,7 @@ __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, in
                 *reinterpret_cast<h8*>(Xp + crow * HXS + off + 64) = lo;
             }
         }
+        if (tp.base != nullptr) write_planes_t(tp, ldp, scale, Tf, TFS, tp.row0 + row0, tp.col0 + 128 * j, tid);  // Tf holds X_j (read-only here)
         LDS_BARRIER();  // Tf, Lf and Xp settled before the next block reads / overwrites them
         TRSM_STAMP(4);  // write-out
     }
@@ -404,8 +435,15 @@ __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, in
 // b [m, w] <- b * L^-T for the w x w lower block at `l` with its inverted 128-blocks `dinv` (w/128 blocks of 128 x 128).
 // m must be a multiple of 32, w a multiple of 128 up to 1024.  planes != NULL: also write the rows' float16 split copy,
 // row i of b at planes + i * ldp (scale as in launch_split_rows).
+static TPlanes make_tplanes(char* planes_t, int64_t tstride, int64_t row0, int64_t col0) {
+    TPlanes tp;
+    tp.base = planes_t; tp.tstride = tstride; tp.row0 = row0; tp.col0 = col0;
+    return tp;
+}
+
 int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv, int64_t w,
-                          char* planes, int64_t ldp, float scale, hipStream_t s) {
+                          char* planes, int64_t ldp, float scale, hipStream_t s, char* planes_t, int64_t tstride, int64_t row0,
+                          int64_t col0) {
     if (m <= 0 || w <= 0) return 0;
     NNGP_REQUIRE(m % PR == 0 && w % 128 == 0 && w <= PWMAX, "trsm_panel: m must be a multiple of 32, w of 128 and <= 1024");
     NNGP_REQUIRE(ldb % 4 == 0 && ldl % 4 == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)l & 15) == 0 && ((uintptr_t)dinv & 15) == 0,
@@ -413,7 +451,10 @@ int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int6
     NNGP_REQUIRE(planes == nullptr || (((uintptr_t)planes & 15) == 0 && ldp % 16 == 0 && ldp >= 4 * w),
                  "trsm_panel: split rows must be 16-byte aligned with ldp >= 4 w");
     NNGP_REQUIRE(m / PR < 2147483647LL, "trsm_panel: too many rows");
-    hipLaunchKernelGGL(k_trsm_panel_f32, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, l, ldl, dinv, (int)w, planes, ldp, scale);
+    NNGP_REQUIRE(planes_t == nullptr || (planes != nullptr && row0 % 32 == 0 && col0 % 128 == 0 && tstride % 16 == 0 && ((uintptr_t)planes_t & 15) == 0),
+                 "trsm_panel: the transposed split copy needs the plain one, rows at multiples of 32 and columns at multiples of 128");
+    hipLaunchKernelGGL(k_trsm_panel_f32, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, l, ldl, dinv, (int)w, planes, ldp, scale,
+                       make_tplanes(planes_t, tstride, row0, col0));
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -436,14 +477,17 @@ int launch_split_diag_frag(const float* a, int64_t ld, int64_t w, float scale, c
 // b [m, w] <- b * L^-T with the left-looking products on the float16 pipe.  lfrag: launch_split_diag_frag of the diagonal block
 // (same scale) -- only its strictly lower 128-blocks are read; dfrag: the inverted 128-blocks in the order the same launch wrote them.
 int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, int64_t w, char* planes,
-                         int64_t ldp, float scale, hipStream_t s) {
+                         int64_t ldp, float scale, hipStream_t s, char* planes_t, int64_t tstride, int64_t row0, int64_t col0) {
     if (m <= 0 || w <= 0) return 0;
     NNGP_REQUIRE(m % PR == 0 && w % 128 == 0 && w <= PWMAX, "trsm_panel_h3: m must be a multiple of 32, w of 128 and <= 1024");
     NNGP_REQUIRE(ldb % 4 == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)dinv & 15) == 0 && lfrag != nullptr &&
                      ((uintptr_t)lfrag & 15) == 0 && ldp % 16 == 0 && ldp >= 4 * w && scale > 0.0f,
                  "trsm_panel_h3: operands must be 16-byte aligned with ldp >= 4 w");
     NNGP_REQUIRE(planes == nullptr || ((uintptr_t)planes & 15) == 0, "trsm_panel_h3: split rows must be 16-byte aligned");
-    hipLaunchKernelGGL(k_trsm_panel_h3, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, lfrag, dinv, (int)w, planes, ldp, scale);
+    NNGP_REQUIRE(planes_t == nullptr || (row0 % 32 == 0 && col0 % 128 == 0 && tstride % 16 == 0 && ((uintptr_t)planes_t & 15) == 0),
+                 "trsm_panel_h3: the transposed split copy needs rows at multiples of 32 and columns at multiples of 128");
+    hipLaunchKernelGGL(k_trsm_panel_h3, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, lfrag, dinv, (int)w, planes, ldp, scale,
+                       make_tplanes(planes_t, tstride, row0, col0));
     NNGP_HIP_CHECK(hipGetLastError());
 #ifdef NNGP_TIMING_KNOBS
     if (NNGP_KNOB(7) == 9) {  // timing study: cycles of workgroup 0 per phase, summed over the launches so far

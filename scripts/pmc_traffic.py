@@ -58,6 +58,11 @@ def main():
                                   "FETCH_SIZE counts what leaves L2 toward the fabric, Infinity-Cache hits included (MI355X_MICROARCH.md), so this is "
                                   "an upper bound on HBM traffic; the x2 applies to 16-byte-per-lane reads, which all of these kernels use")
     out["cholesky_bytes"] = sum(out["kernels"][k]["fetch_bytes"] + out["kernels"][k]["write_bytes"] for k in chol)
+    # fingerprint of the kernel sources these counters were taken with: bench.py only quotes the traffic while they are unchanged
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nngp-src_amd", "csrc")
+    out["sources_sha16"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
+                            for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))}
     print(json.dumps(out, indent=1))
 
 

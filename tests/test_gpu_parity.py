@@ -543,6 +543,31 @@ def test_blocked_solves_of_the_posterior_against_scipy(n, rows, wide):
         _lib.load(knobs=True).nngp_debug_set(9, 0)
 
 
+@pytest.mark.parametrize("n", [9300, 12288])
+def test_transposed_split_copy_from_the_panel_solves_is_the_separate_pass_bit_for_bit(n):
+    """Round 4: the Cholesky's fused panel solves also write the TRANSPOSED float16-split copy of L (operand of the posterior's
+    "B L^-1" solves) instead of a separate pass over the finished factor beside a predict's first solve (k_split_lower_t; debug key
+    9 = 8 restores it, knobs build).  Same values, same rounding: the posterior of a block large enough for the float16-pipe
+    solves must come out bit for bit the same, and so must both halves of the solve through nngp_model_apply_factor."""
+    from nngp_src_amd import _lib
+    x, y = synth.synthetic_queries(n, 24, seed=71)
+    xt, _ = synth.synthetic_queries(1024, 24, seed=72)
+    lib = _lib.load(knobs=True)
+    B = torch.randn((1024, n), device=G.dev(), dtype=torch.float32)
+    out = {}
+    for key9 in (8, 0):
+        lib.nngp_debug_set(9, key9)  # read by the factorisation
+        try:
+            model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
+            mean, var = model.predict(xt, cov="diag")
+            z = model.apply_factor(B.clone(), both_halves=True).clone()
+            out[key9] = (mean, var, z)
+            model.close()
+        finally:
+            lib.nngp_debug_set(9, 0)
+    assert np.array_equal(out[0][0], out[8][0]) and np.array_equal(out[0][1], out[8][1]) and torch.equal(out[0][2], out[8][2])
+
+
 def test_triangular_inverse_blocks_skip_their_zero_tiles_bit_for_bit():
     """Round 4: the blocked solves multiply by the inverted diagonal blocks with a float32 GEMM that walks, per column tile, only the
     k tiles where the (triangular) block is non-zero.  The skipped terms are exact zeros: the solve must return the bits of the
