@@ -160,6 +160,64 @@ def bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, 
     dist.destroy_process_group()
 
 
+def bench_shard32(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, m, desc):
+    """Opt-in layout (SURVEY.md 8e with the exchange it sizes; nngp-src_amd/shard32.py): every rank keeps its float64 kernel rows, ONE
+    all-gather carries the float32 factor input, the Cholesky is replicated (NNGP_DIST_CHOL=1: 1-D block-cyclic), the alpha CG's
+    matrix-vector product and the covariance's residual product are sharded by the rows a rank holds.  A step = sharded kernel build +
+    float32 all-gather + factorisation + CG + mean and level-1 variance of the M test queries (dealt to the ranks)."""
+    import torch
+    import torch.distributed as dist
+    from nngp_src_amd import shard32
+    if get != "nngp":
+        raise SystemExit("bench.py --mode shard32: the row-sharded covariance is the NNGP one")
+    ops = shard32.HipRowOps(n, d, [1.0] * (n_relu + 1), [0.0] * (n_relu + 1), diag_reg=1e-3, world=world)
+    dchol = os.environ.get("NNGP_DIST_CHOL", "0") == "1"
+
+    def step():
+        gp = shard32.RowShardedGP(ops, x, y, distributed_cholesky=dchol).fit()
+        gp.predict(xt, cov=True)
+        return gp
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gp = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        fl = flop_model(n, d, m, n_relu)
+        ms = float(t.item()) / args.steps * 1e3
+        chunk = -(-n // world)
+        print(json.dumps({
+            "metric": "NNGP kernel-build + GP-solve wall-clock (ms) and GFLOP/s at N train queries",
+            "value": round(fl["total"] / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (Cholesky products as split f16 x3, f32 accumulate; f64 build/CG/means; float64 residual product on the float64 MFMA)",
+            "data": "synthetic",
+            "config": {"workload": desc, "N": n, "d": d, "n_relu": n_relu, "get": get, "M_test": m,
+                       "parallelism": "row-block kernel shard x%d, float64 rows kept local; ONE in-place all-gather of the float32 factor input; %s "
+                                      "Cholesky; CG matrix-vector product and residual product sharded by rows (one N-vector / M x N/G all-gather per use)"
+                                      % (world, "1-D block-cyclic" if dchol else "replicated")},
+            "fit_info": {"cg_iters": gp.cg_iters, "rel_residual": gp.relres, "reg": gp.reg, "shift_scale": gp.shift_scale,
+                         "alpha_l2": float(torch.linalg.vector_norm(gp.alpha).item())},
+            "shard": {"ranks_seen": world, "layout": "shard32",
+                      "allgather_GB_received_per_rank": round(gp.exchanged_bytes["factor_input_received_per_rank"] / 1e9, 4),
+                      "float64_kernel_allgather_GB_would_be": round((world - 1) * chunk * ops.factor_input_buffer().shape[1] * 8 / 1e9, 4),
+                      "cg_vector_GB_received_per_rank": round(gp.exchanged_bytes["cg_vectors_received_per_rank"] / 1e9, 6),
+                      "backend": dist.get_backend() if world > 1 else "none"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def launch_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher around it: start the ranks as a CHILD `torch.distributed.run` of this same
     file with the same arguments, relay rank 0's JSON line and exit with the child's code.  Runs before this process has imported
@@ -236,7 +294,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg3 on one GPU, cfg4 on several")
-    ap.add_argument("--mode", default=os.environ.get("NNGP_DIST_MODE", "shard"), choices=["shard", "replicate", "grid2d"],
+    ap.add_argument("--mode", default=os.environ.get("NNGP_DIST_MODE", "shard"), choices=["shard", "replicate", "grid2d", "shard32"],
                     help="multi-GPU layout (default: the north star's row-block shard + all-gather; grid2d: the 2-D block-cyclic "
                          "fit of dist2d.py, no rank holding the whole kernel or factor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -286,6 +344,8 @@ def main():
     xt, _ = synth.synthetic_queries(m, d, seed=1, join_block=join_block)
     if world > 1 and args.mode == "grid2d":
         return bench_grid2d(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, m, desc)
+    if args.mode == "shard32" and (world > 1 or os.environ.get("NNGP_SHARD32_SINGLE") == "1"):
+        return bench_shard32(args, world, rank, dev, cfg_name, x, y, xt, n, d, n_relu, get, m, desc)
     xd, yd, xtd = (torch.from_numpy(a).to(dev) for a in (x, y, xt))
     m0, m1 = distributed.row_partition(m, world, rank)
     xt_local = xtd[m0:m1].contiguous()

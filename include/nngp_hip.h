@@ -147,6 +147,25 @@ int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** d
 /* The float64 train-train kernel buffer (device pointer, leading dimension in elements) so the host
  * can all-gather row blocks over RCCL between build_rows and factor. */
 int nngp_model_kernel_buffer(nngp_model* m, double** k64, int64_t* ld);
+/* ---- the row-sharded layout (round 4, nngp-src_amd/shard32.py): what travels between GPUs is the FLOAT32 factor input
+ * (4 N^2 / G bytes per rank, the exchange 8e sizes), and each rank's float64 kernel rows -- the operand of the CG's matrix-vector product
+ * and of the covariance's residual product -- stay where nt.batch's device slot built them (reference: nt.batch(kernel_fn,
+ * device_count), train.py:166-168).  After nngp_model_build_rows(row_begin, row_end):
+ *   _factor_input_rows   a32 rows [row_begin, row_end) = float32(K rows) + reg * shift_scale on the diagonal (lower tiles; shift_scale
+ *                        >= 1: a caller that saw clamped pivots redoes the exchange with a larger shift, as nngp_model_factor does alone);
+ *                        marks the model's float64 kernel as partial: nngp_model_factor then never rebuilds the input from it
+ *   (all-gather of the float32 buffer -- nngp_model_factor_buffers gives it -- e.g. nngp_allgather_rows with NNGP_DTYPE_F32)
+ *   _factor_input_complete  every row is in place: the next nngp_model_factor / _factor_begin only adds the padding
+ *   _precond             z = (L L^T)^-1 r with the float32 factor (r, z: n doubles): the preconditioner of a CG driven by the caller,
+ *   _matvec_rows         q[0 : row_end - row_begin] = K[row_begin : row_end, :] p (no regulariser): its sharded matrix-vector product
+ *   _set_alpha           installs the solution (n x ny doubles, device) with the solve's iteration count and relative residual:
+ *                        nngp_model_predict(..., NNGP_COV_NONE) then serves means; covariances of this layout are formed by the
+ *                        caller from nngp_model_apply_factor, nngp_kernel_build and nngp_gemm_nt_f64 on its row block (shard32.py). */
+int nngp_model_factor_input_rows(nngp_model* m, int64_t row_begin, int64_t row_end, double shift_scale, void* stream);
+int nngp_model_factor_input_complete(nngp_model* m);
+int nngp_model_precond(nngp_model* m, const double* r, double* z, void* stream);
+int nngp_model_matvec_rows(nngp_model* m, const double* p, double* q, int64_t row_begin, int64_t row_end, void* stream);
+int nngp_model_set_alpha(nngp_model* m, const double* alpha, int32_t iters, double rel_residual, void* stream);
 int nngp_model_info(nngp_model* m, nngp_fit_info* info /* host */);
 /* Live timing of the path's dominant kernel, the split-float16 trailing update of the Cholesky (k_gemm_nt_h3, lower):
  * with the timer on, nngp_model_factor brackets every such launch with a pair of HIP events on the stream it is launched

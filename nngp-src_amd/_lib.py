@@ -26,7 +26,8 @@ ABI_SYMBOLS = (
     "nngp_model_factor", "nngp_model_factor_begin", "nngp_model_factor_panel", "nngp_model_factor_update",
     "nngp_model_factor_end", "nngp_model_factor_buffers", "nngp_model_solve", "nngp_model_append", "nngp_model_kernel_buffer", "nngp_model_info",
     "nngp_model_alpha", "nngp_model_predict", "nngp_model_set_refine", "nngp_model_cov_iters", "nngp_model_sweep_estimate", "nngp_model_factor_shift", "nngp_model_prepare_serving", "nngp_potrf_f32", "nngp_gemm_nt_f32",
-    "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_model_apply_factor", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
+    "nngp_gemm_nt_h3", "nngp_gemm_nt_f64", "nngp_trsm_rlt_f32", "nngp_model_apply_factor",
+    "nngp_model_factor_input_rows", "nngp_model_factor_input_complete", "nngp_model_precond", "nngp_model_matvec_rows", "nngp_model_set_alpha", "nngp_encoder_create", "nngp_encoder_destroy", "nngp_encoder_dim",
     "nngp_encoder_encode", "nngp_comm_unique_id", "nngp_comm_create", "nngp_comm_destroy", "nngp_comm_library",
     "nngp_allgather_rows", "nngp_bcast", "nngp_model_update_timer", "nngp_model_update_timer_read", "nngp_symv_f64",
     "nngp_pool_select", "nngp_model_update_timer_bytes", "nngp_model_factor_update_cols", "nngp_gemm_nt_i8s", "nngp_model_residual_timer", "nngp_model_residual_timer_read", "nngp_model_residual_floor",
@@ -123,6 +124,11 @@ def bind_prototypes(lib, knobs: bool = False):
                                     ctypes.c_float, i32, vp]
     lib.nngp_trsm_rlt_f32.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp]
     lib.nngp_model_apply_factor.argtypes = [vp, vp, i64, i32, vp]
+    lib.nngp_model_factor_input_rows.argtypes = [vp, i64, i64, ctypes.c_double, vp]
+    lib.nngp_model_factor_input_complete.argtypes = [vp]
+    lib.nngp_model_precond.argtypes = [vp, vp, vp, vp]
+    lib.nngp_model_matvec_rows.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.nngp_model_set_alpha.argtypes = [vp, vp, i32, ctypes.c_double, vp]
     lib.nngp_comm_unique_id.argtypes = [vp]
     lib.nngp_comm_create.argtypes = [ctypes.POINTER(vp), vp, i32, i32]
     lib.nngp_comm_destroy.argtypes = [vp]

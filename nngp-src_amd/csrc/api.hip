@@ -64,6 +64,10 @@ struct nngp_model {
     int64_t ld = 0;  // leading dimension of k64 / a32 = np_cap, fixed so that rows can be appended in place
     bool have_train = false, built = false, factored = false, solved = false;
     bool a32_built = false;  // the kernel build also wrote float32(K) + reg I on the lower tiles of a32 (fused factor input)
+    // Row-sharded layout (round 4, nngp-src_amd/shard32.py): this rank's float64 kernel rows stay local, the float32 factor input is what
+    // travels.  a32_complete: every row of a32 is in place (converted here or gathered) -- factor_begin only adds the padding;
+    // k64_partial: k64 holds this rank's rows only -- no refactoring from it, no replicated CG, no covariance inside nngp_model_predict.
+    bool a32_complete = false, k64_partial = false;
 
     // training-side buffers
     double* x = nullptr;      // [n_cap, d]
@@ -851,6 +855,8 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     a.ld64 = a.ld32 = m->ld;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
     m->a32_built = false;
+    m->a32_complete = false;
+    m->k64_partial = false;
     m->i8.k.ready = false;
     m->i8_checked = m->i8_distrusted = false;
     m->i8_guard_pending = false;
@@ -875,8 +881,9 @@ int nngp_model_factor_begin(nngp_model* m, void* stream) {
     // a32 = float32(K) + reg I on the lower tiles; if the build already wrote it, only the last (partial + padding)
     // block row is left
     NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, m->n, m->np, m->reg_fac, m->reg_fac + m->trace_mean, s,
-                                 m->a32_built ? (m->n / TB) * TB : 0));
+                                 m->a32_complete ? m->n : m->a32_built ? (m->n / TB) * TB : 0));  // (rows >= n: padding only, no read of k64)
     m->a32_built = false;  // the factorisation overwrites a32
+    m->a32_complete = false;
     NNGP_HIP_CHECK(hipMemsetAsync(m->clamped, 0, sizeof(int32_t), s));
     m->tri.bs = triinv_block(m->np);
     m->factored = m->solved = false;
@@ -905,6 +912,48 @@ int nngp_model_factor_update_cols(nngp_model* m, int64_t panel_col0, int64_t pan
     NNGP_REQUIRE(m != nullptr && m->built, "factor_update_cols: build the kernel rows first");
     NNGP_REQUIRE(ncols >= 0 && (ncols == 0 || cols != nullptr), "factor_update_cols: bad column list");
     return potrf_update_cols_f32(m->a32, m->np, m->ld, panel_col0, panel_width, cols, ncols, width, (hipStream_t)stream, &m->split);
+}
+
+int nngp_model_factor_input_rows(nngp_model* m, int64_t row_begin, int64_t row_end, double shift_scale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->built, "factor_input_rows: build the kernel rows first");
+    NNGP_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= m->n && shift_scale >= 1.0, "factor_input_rows: bad row range or shift");
+    NNGP_TRY(drop_pending_solve(m));
+    m->reg_fac = m->reg * shift_scale;
+    m->k64_partial = true;
+    return launch_factor_input(m->k64, m->ld, m->a32, m->ld, m->n, m->np, m->reg_fac, m->reg_fac + m->trace_mean, s, row_begin, row_end);
+}
+
+int nngp_model_factor_input_complete(nngp_model* m) {
+    NNGP_REQUIRE(m != nullptr && m->built, "factor_input_complete: build the kernel rows first");
+    m->a32_complete = true;
+    return 0;
+}
+
+int nngp_model_precond(nngp_model* m, const double* r, double* z, void* stream) {
+    NNGP_REQUIRE(m != nullptr && m->factored, "precond: factor first");
+    NNGP_REQUIRE(r != nullptr && z != nullptr, "precond: NULL argument");
+    return precond_apply(m->a32, m->ld, m->tri, m->n, m->np, r, z, m->pcg, (hipStream_t)stream);
+}
+
+int nngp_model_matvec_rows(nngp_model* m, const double* p, double* q, int64_t row_begin, int64_t row_end, void* stream) {
+    NNGP_REQUIRE(m != nullptr && m->built, "matvec_rows: build the kernel rows first");
+    NNGP_REQUIRE(p != nullptr && q != nullptr && 0 <= row_begin && row_begin <= row_end && row_end <= m->n, "matvec_rows: bad arguments");
+    return launch_gemv_f64(m->k64 + row_begin * m->ld, m->ld, row_end - row_begin, m->n, p, 1, q, 1, 0.0, (hipStream_t)stream);
+}
+
+int nngp_model_set_alpha(nngp_model* m, const double* alpha, int32_t iters, double rel_residual, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    NNGP_REQUIRE(m != nullptr && m->factored && alpha != nullptr, "set_alpha: factor first");
+    NNGP_TRY(drop_pending_solve(m));
+    NNGP_HIP_CHECK(hipMemcpyAsync(m->alpha, alpha, sizeof(double) * m->n * m->ny, hipMemcpyDeviceToDevice, s));
+    m->solved = true;
+    m->solve_pending = false;
+    m->cg_partial = false;
+    m->have_alpha_event = false;  // alpha was written on the caller's stream, in order
+    m->iters = iters;
+    m->relres = rel_residual;
+    return 0;
 }
 
 int nngp_model_factor_end(nngp_model* m, void* stream) {
@@ -946,7 +995,7 @@ int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** d
 int nngp_model_factor(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor: build the kernel rows first");
-    m->reg_fac = m->reg;
+    if (!m->k64_partial) m->reg_fac = m->reg;  // (row-sharded layout: nngp_model_factor_input_rows chose the shift)
     set_split_scale(m);
     for (int attempt = 0;; ++attempt) {
         NNGP_TRY(nngp_model_factor_begin(m, stream));
@@ -954,7 +1003,7 @@ int nngp_model_factor(nngp_model* m, void* stream) {
         int32_t cl = 0;
         NNGP_HIP_CHECK(hipMemcpyAsync(&cl, m->clamped, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         NNGP_HIP_CHECK(hipStreamSynchronize(s));
-        if (cl == 0 || attempt == 4 || NNGP_KNOB(6) == 1) break;
+        if (cl == 0 || attempt == 4 || NNGP_KNOB(6) == 1 || m->k64_partial) break;  // (row-sharded layout: the caller redoes the exchange with a larger shift)
         m->reg_fac *= 16.0;
         set_split_scale(m);
     }

@@ -329,12 +329,15 @@ int pcg_finish(const double* k64, int64_t ld, int64_t n, double reg, const float
 int pcg_solve(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32,
               const TriInv& ti, int64_t np, const double* bcol, double* xcol, PcgWork& w, int max_iters,
               double tol, int* iters_out, double* relres_out, hipStream_t s);
+// z = (L L^T)^-1 r with the float32 factor (the CG's preconditioner on its own: the row-sharded layout drives the CG from the host side)
+int precond_apply(const float* l32, int64_t ld32, const TriInv& ti, int64_t n, int64_t np, const double* r, double* z, PcgWork& w,
+                  hipStream_t s);
 
 // ---- posterior.hip ----
 int launch_convert_f64_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
                            int64_t rows_p, int64_t cols_p, hipStream_t s);
 int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np,
-                        double reg, double pad_diag, hipStream_t s, int64_t row_begin = 0);
+                        double reg, double pad_diag, hipStream_t s, int64_t row_begin = 0, int64_t row_end = -1);  // rows [row_begin, row_end) (-1: to np)
 int launch_mirror_rows_f64(double* k, int64_t ld, int64_t n0, int64_t n1, hipStream_t s);
 int launch_row_sqsum_f32(const float* v, int64_t ld, int64_t rows, int64_t cols, const double* base,
                          double* out, hipStream_t s);

@@ -462,11 +462,12 @@ int launch_mirror_rows_f64(double* k, int64_t ld, int64_t n0, int64_t n1, hipStr
 }
 
 int launch_factor_input(const double* k64, int64_t ld64, float* a32, int64_t ld32, int64_t n, int64_t np, double reg,
-                        double pad_diag, hipStream_t s, int64_t row_begin) {
+                        double pad_diag, hipStream_t s, int64_t row_begin, int64_t row_end) {
     NNGP_REQUIRE(np % TB == 0 && np <= 65535LL * 1024 && row_begin >= 0, "factor_input: bad padded size %lld", (long long)np);
+    if (row_end < 0 || row_end > np) row_end = np;
     // grid.y is limited to 65535 rows per launch
-    for (int64_t r0 = row_begin; r0 < np; r0 += 65535) {
-        const int64_t rows = (np - r0 < 65535) ? np - r0 : 65535;
+    for (int64_t r0 = row_begin; r0 < row_end; r0 += 65535) {
+        const int64_t rows = (row_end - r0 < 65535) ? row_end - r0 : 65535;
         hipLaunchKernelGGL(k_factor_input, dim3((unsigned)((np + 1023) / 1024), (unsigned)rows), dim3(256), 0, s,
                            k64, ld64, a32, ld32, n, np, reg, pad_diag, r0);
     }

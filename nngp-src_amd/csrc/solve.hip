@@ -528,6 +528,16 @@ int pcg_iteration(const double* k64, int64_t ld, int64_t n, double reg, const fl
 }
 }  // namespace
 
+int precond_apply(const float* l32, int64_t ld32, const TriInv& ti, int64_t n, int64_t np, const double* r, double* z, PcgWork& w,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks256(np)), dim3(256), 0, s, r, w.f32a, n, np);
+    NNGP_TRY(trsv_forward_f32(l32, ld32, ti, np, w.f32a, w.f32b, s));
+    NNGP_TRY(trsv_backward_f32(l32, ld32, ti, np, w.f32b, w.f32c, s));
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks256(n)), dim3(256), 0, s, w.f32c, z, n);
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int pcg_begin(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
               int64_t np, const double* bcol, double* xcol, PcgWork& w, int ahead, hipStream_t s) {
     NNGP_REQUIRE(ahead >= 0 && ahead <= kPcgMaxAhead, "pcg_begin: at most %d iterations ahead", kPcgMaxAhead);

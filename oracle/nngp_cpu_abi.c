@@ -339,6 +339,12 @@ int nngp_model_sweep_estimate(nngp_model* m, double* row_rel, double* var_rel) {
 /* ---- no CPU counterpart: exported so that a binding of the header links, answering -2 ---- */
 int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, int64_t b, void* stream) { (void)m; (void)x_new; (void)y_new; (void)b; (void)stream; NOT_HERE("nngp_model_append"); }
 int nngp_model_factor_begin(nngp_model* m, void* stream) { (void)m; (void)stream; NOT_HERE("nngp_model_factor_begin"); }
+/* the row-sharded layout's entry points (float32 exchange, host-driven CG) are multi-GPU plumbing: not in the CPU build */
+int nngp_model_factor_input_rows(nngp_model* m, int64_t row_begin, int64_t row_end, double shift_scale, void* stream) { (void)m; (void)row_begin; (void)row_end; (void)shift_scale; (void)stream; NOT_HERE("nngp_model_factor_input_rows"); }
+int nngp_model_factor_input_complete(nngp_model* m) { (void)m; NOT_HERE("nngp_model_factor_input_complete"); }
+int nngp_model_precond(nngp_model* m, const double* r, double* z, void* stream) { (void)m; (void)r; (void)z; (void)stream; NOT_HERE("nngp_model_precond"); }
+int nngp_model_matvec_rows(nngp_model* m, const double* p, double* q, int64_t row_begin, int64_t row_end, void* stream) { (void)m; (void)p; (void)q; (void)row_begin; (void)row_end; (void)stream; NOT_HERE("nngp_model_matvec_rows"); }
+int nngp_model_set_alpha(nngp_model* m, const double* alpha, int32_t iters, double rel_residual, void* stream) { (void)m; (void)alpha; (void)iters; (void)rel_residual; (void)stream; NOT_HERE("nngp_model_set_alpha"); }
 int nngp_model_factor_panel(nngp_model* m, int64_t col0, int64_t width, void* stream) { (void)m; (void)col0; (void)width; (void)stream; NOT_HERE("nngp_model_factor_panel"); }
 int nngp_model_factor_update(nngp_model* m, int64_t pc, int64_t pw, int64_t c0, int64_t w, void* stream) { (void)m; (void)pc; (void)pw; (void)c0; (void)w; (void)stream; NOT_HERE("nngp_model_factor_update"); }
 int nngp_model_factor_update_cols(nngp_model* m, int64_t panel_col0, int64_t panel_width, const int64_t* cols, int32_t ncols, int64_t width, void* stream) { (void)m; (void)panel_col0; (void)panel_width; (void)cols; (void)ncols; (void)width; (void)stream; NOT_HERE("nngp_model_factor_update_cols"); }

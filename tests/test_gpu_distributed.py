@@ -201,6 +201,70 @@ def test_library_owned_rccl_communicator_on_two_gpus(tmp_path, bcast):
             f.write("library-owned RCCL communicator at world = 2 (NNGP_BCAST=%s): all-gather, broadcast, sharded fit == single-GPU fit\n" % bcast)
 
 
+def _worker_shard32(rank, world, port, n, m, d, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nngp_src_amd import shard32, synth
+        x, y = synth.synthetic_queries(n, d, seed=0)
+        xt, _ = synth.synthetic_queries(m, d, seed=1)
+        ops = shard32.HipRowOps(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3, world=world)
+        gp = shard32.RowShardedGP(ops, x, y).fit()
+        assert gp.relres <= 1e-10 and gp.cg_iters <= 10 and gp.shift_scale == 1.0, (gp.relres, gp.cg_iters, gp.shift_scale)
+        mean, var = gp.predict(xt, cov=True)
+        # the model itself serves means from the installed alpha (its float64 kernel holds this rank's rows only)
+        m_model = ops.model.predict(xt, cov=False)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean, var=var, alpha=ops.to_host(gp.alpha), m_model=np.ravel(m_model),
+                 recv=gp.exchanged_bytes["factor_input_received_per_rank"], iters=gp.cg_iters)
+        ops.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,m", [(2, 2048 + 77, 70), (1, 1500, 40), (3, 1000, 33)])
+def test_row_sharded_float32_exchange_on_the_gpu_matches_single_gpu_and_oracle(tmp_path, world, n, m):
+    """SURVEY.md 8e with the exchange it sizes (round 4, nngp-src_amd/shard32.py): every rank keeps its float64 kernel rows, ONE
+    all-gather carries the float32 factor input, the CG's matrix-vector product and the covariance's residual product are sharded by the
+    rows a rank holds.  HIP kernels do the per-rank work (kernel rows, factor input, MFMA Cholesky, preconditioner, blocked solves,
+    float64 GEMM), gloo the collectives between ranks sharing the test box's one GPU.  alpha, means and level-1 variances against the
+    single-GPU model AND the float64 oracle; the bytes received for the factor input are half the float64 kernel's."""
+    d = 24
+    sys.path.insert(0, ROOT)
+    from nngp_src_amd import synth
+    from nngp_src_amd.model import GPModel
+    mp.spawn(_worker_shard32, args=(world, _free_port(), n, m, d, str(tmp_path)), nprocs=world, join=True)
+    x, y = synth.synthetic_queries(n, d, seed=0)
+    xt, _ = synth.synthetic_queries(m, d, seed=1)
+    ref = GPModel(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    m0, v0 = ref.predict(xt, cov="diag")
+    a0 = ref.alpha().cpu().numpy().ravel()
+    for p_ in (ROOT, os.path.join(ROOT, "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import nngp_oracle as o
+    post = o.Posterior(x, y, o.make_arch(1), diag_reg=1e-3)
+    m_or, c_or = post.predict(xt, "nngp", True)
+    a_or = post._factor("nngp")[2].ravel()
+    chunk = (n + world - 1) // world
+    for r in range(world):
+        g = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.linalg.norm(g["alpha"] - a0) <= 1e-8 * np.linalg.norm(a0)
+        assert np.linalg.norm(g["alpha"] - a_or) <= 1e-7 * np.linalg.norm(a_or)
+        assert np.linalg.norm(g["mean"] - np.ravel(m0)) <= 1e-8 * np.linalg.norm(m0)
+        assert np.linalg.norm(g["m_model"] - np.ravel(m0)) <= 1e-8 * np.linalg.norm(m0)
+        assert np.linalg.norm(g["mean"] - m_or.ravel()) <= 1e-6 * np.linalg.norm(m_or)   # north-star gate: 1e-4
+        np.testing.assert_allclose(g["var"], v0, rtol=1e-4)
+        np.testing.assert_allclose(g["var"], np.diag(c_or), rtol=3e-4)                    # gate: 1e-3
+        if world > 1:
+            ld = ((chunk * world + 127) // 128) * 128
+            assert int(g["recv"]) == (world - 1) * chunk * ld * 4
+
+
 def _worker2d(rank, world, port, pr, pc, n, d, nb, out_dir):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
