@@ -176,6 +176,7 @@ struct nngp_model {
         dev_free(pcg.r); dev_free(pcg.z); dev_free(pcg.p); dev_free(pcg.q); dev_free(pcg.xcol); dev_free(pcg.bcol);
         dev_free(pcg.f32a); dev_free(pcg.f32b); dev_free(pcg.f32c); dev_free(pcg.scal); dev_free(pcg.symv_part); dev_free(pcg.dot_part); dev_free(pcg.dot_ctr);
         if (pcg.host_scal) (void)hipHostFree(pcg.host_scal);
+        if (pcg.iter_graph) (void)hipGraphExecDestroy(pcg.iter_graph);
         dev_free(tri.tinv); dev_free(tri.xinv); dev_free(tri.partial); dev_free(tri.tmp);
         lookahead_destroy(la);
         if (solve_stream) (void)hipStreamDestroy(solve_stream);

@@ -42,6 +42,7 @@ void set_error(const char* fmt, ...);
 //   9  round 4, posterior solves: 2 = 2048-wide inverted blocks / two 1024-column panels per step of the blocked solves from np = 8192 on
 //      (measured: posterior -0.5 ms, block inverses +1.1 ms at N = 32768 -- off)
 //  10  block columns from the end where key 8 = 32 issues the inverses; 11  priority of that side stream; 12  print the schedule's stream end times
+//  13  compute units the posterior solves' update grids leave to the alpha CG; 14  2 = CG iterations replayed from a hipGraph
 #ifdef NNGP_TIMING_KNOBS
 extern std::atomic<int> g_knobs[16];
 #define NNGP_KNOB(i) (nngp::g_knobs[i].load(std::memory_order_relaxed))
@@ -320,6 +321,12 @@ struct PcgWork {
     int64_t symv_np = 0;          // its np (0: not allocated -> plain GEMV)
     double* scal;       // device scalars [32]: 0..4 CG scalars, 6..7 trace / max of the diagonal, 8.. CG residual history
     double* host_scal;  // pinned host [32]
+    // One CG iteration (from the second on: ~170 launches at N = 32768) captured once as a hipGraph and replayed (round 4); the key says
+    // what the captured launches were built for -- any change of it (another size, other buffers) captures again.
+    hipGraphExec_t iter_graph = nullptr;
+    const void* graph_key[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t graph_dims[4] = {0, 0, 0, 0};
+    double graph_reg = 0.0;  // (the regulariser is a by-value kernel argument)
 };
 int pcg_begin(const double* k64, int64_t ld, int64_t n, double reg, const float* l32, int64_t ld32, const TriInv& ti,
               int64_t np, const double* bcol, double* xcol, PcgWork& w, int ahead, hipStream_t s);

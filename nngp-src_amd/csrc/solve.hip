@@ -576,7 +576,38 @@ int pcg_finish(const double* k64, int64_t ld, int64_t n, double reg, const float
             }
         }
         for (int it = ahead; it < max_iters && !done; ++it) {
-            NNGP_TRY(pcg_iteration(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, it, w.scal + 3, s));
+            // Iterations >= 1 launch the same kernels with the same arguments: they can be captured once as a hipGraph and replayed
+            // (debug key 14 = 2).  Measured (round 4, scripts/cov_alone.py, N = 32768): CG alone 11.8 ms either way, covariance + mean with
+            // the CG beside it 35.7 ms either way -- the ~170 launches of an iteration are bound by the GPU's own kernel-to-kernel
+            // latency and HBM, not by the host's enqueue cost; plain launches stay.
+            const bool graphable = it >= 1 && NNGP_KNOB(14) == 2;
+            const void* key[4] = {k64, l32, xcol, w.r};
+            const int64_t dims[4] = {n, np, ti.bs, ld};
+            if (graphable && w.iter_graph != nullptr && (memcmp(key, w.graph_key, sizeof(key)) != 0 || memcmp(dims, w.graph_dims, sizeof(dims)) != 0 || w.graph_reg != reg)) {
+                (void)hipGraphExecDestroy(w.iter_graph);
+                w.iter_graph = nullptr;
+            }
+            if (graphable && w.iter_graph == nullptr) {
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int rc_it = pcg_iteration(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, it, w.scal + 3, s);
+                    const hipError_t ec = hipStreamEndCapture(s, &g);
+                    if (rc_it == 0 && ec == hipSuccess && g != nullptr && hipGraphInstantiate(&w.iter_graph, g, nullptr, nullptr, 0) == hipSuccess) {
+                        memcpy(w.graph_key, key, sizeof(key));
+                        memcpy(w.graph_dims, dims, sizeof(dims));
+                        w.graph_reg = reg;
+                    } else {
+                        w.iter_graph = nullptr;
+                    }
+                    if (g != nullptr) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                }
+            }
+            if (graphable && w.iter_graph != nullptr) {
+                NNGP_HIP_CHECK(hipGraphLaunch(w.iter_graph, s));
+            } else {
+                NNGP_TRY(pcg_iteration(k64, ld, n, reg, l32, ld32, ti, np, xcol, w, it, w.scal + 3, s));
+            }
             NNGP_HIP_CHECK(hipMemcpyAsync(w.host_scal + 3, w.scal + 3, sizeof(double), hipMemcpyDeviceToHost, s));
             NNGP_HIP_CHECK(hipStreamSynchronize(s));
             iters = it + 1;
