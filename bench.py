@@ -528,7 +528,7 @@ def main():
                        "precision": "float64 kernel build + CG residual; float32 Cholesky (preconditioner) whose trailing updates run "
                                     "as split-float16 MFMA products (hi+lo, 3 per term, float32 accumulate); float64 means; variances: "
                                     "float32-grade solves on the float16 pipe + one float64-GRADE residual product on the int8 pipe "
-                                    "(operands cut into exact 8-bit digit planes, 15 exact plane products, float64 combination; level 1)"},
+                                    "(operands cut into exact 8-bit digit planes, 12 exact plane products, float64 combination; level 1)"},
             "roofline": None,  # filled in below: the dominant kernel when the library timed it, else the stage
             # Cholesky stage = the dominant cost.  `achieved` = algorithmic F_C / stage time.  Its matrix work runs on the
             # float16 pipe at 3 products per float32-grade term, so the hardware peak for it is PEAK_F16 / 3; the
@@ -549,7 +549,7 @@ def main():
                                    "frac": round(post_tflops / PEAK_F32_MFMA_TFLOPS, 4), "stage_ms": round(post_ms, 3),
                                    "work": "2NMd + 4NM + N^2 M (cross kernel, mean, variances) for this rank's %d test rows x world" % (m1 - m0)
                                            if world > 1 else "2NMd + 4NM + N^2 M (cross kernel, mean, variances)",
-                                   "note": "algorithmic count; executed: one float64-grade residual product 2 N^2 M as 15 exact int8 plane "
+                                   "note": "algorithmic count; executed: one float64-grade residual product 2 N^2 M as 12 exact int8 plane "
                                            "products (k_gemm_nt_i8s, see roofline_residual; until round 3 one float64 MFMA product on the "
                                            "78.6 TF/s pipe), three float32-grade triangular solves N^2 M each on the float16 pipe, the "
                                            "alpha CG on HBM"},

@@ -68,6 +68,7 @@ struct nngp_model {
     // travels.  a32_complete: every row of a32 is in place (converted here or gathered) -- factor_begin only adds the padding;
     // k64_partial: k64 holds this rank's rows only -- no refactoring from it, no replicated CG, no covariance inside nngp_model_predict.
     bool a32_complete = false, k64_partial = false;
+    bool k64_symmetric = false;  // k64 came from ONE symmetric build (mirrored tiles: bitwise symmetric) -- its digit planes can be cut from the lower triangle
 
     // training-side buffers
     double* x = nullptr;      // [n_cap, d]
@@ -143,6 +144,7 @@ struct nngp_model {
     hipEvent_t ev_guard = nullptr;
     bool i8_guard_pending = false;
     bool i8_want_fine = false;  // sticky: see i8s_planes_policy
+    bool i8_fuse_request = false, i8_fuse_done = false;  // level-1 variance: row statistics + float32 copy from the combination pass (I8Fuse)
     bool i8_suspended = false;   // prepare_serving: the explicit inverse is refined against residuals of the float64 pipe itself  // prepare_serving: the explicit inverse is refined against float64 residuals proper
 
     double reg = 0.0, trace_mean = 0.0, relres = 0.0;
@@ -155,6 +157,12 @@ struct nngp_model {
     // own stream when alpha is first needed -- inside predict AFTER the covariance work has been enqueued, so that the
     // HBM-bound CG (float64 GEMV + float32 TRSVs) overlaps the MFMA-bound covariance products.
     hipStream_t solve_stream = nullptr;
+    // The inverted 1024-blocks of the factor (tri: CG preconditioner, blocked solves) are built lazily: nngp_model_factor_end only marks
+    // them stale; a predict right after the fit builds them on the look-ahead's panel stream beside its cross-kernel build (a chain of
+    // ~17 small launches, 0.5 ms at N = 32768, that leaves the chip idle when it runs in line); every other consumer builds them in
+    // order.  tri_join() is the one gate: every reader of `tri` passes it on the stream it reads from.
+    bool tri_stale = false, tri_pending = false;
+    hipEvent_t ev_tri = nullptr, ev_tri_fork = nullptr;
     hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
     hipEvent_t ev_lt = nullptr;  // orders the split copy of L^T written on solve_stream (apply_inverse_f32)
     hipEvent_t ev_predict = nullptr;  // end of the last predict on its stream: it reads alpha and the CG residual
@@ -182,12 +190,14 @@ struct nngp_model {
         if (solve_stream) (void)hipStreamDestroy(solve_stream);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_lt) (void)hipEventDestroy(ev_lt);
+        if (ev_tri) (void)hipEventDestroy(ev_tri);
+        if (ev_tri_fork) (void)hipEventDestroy(ev_tri_fork);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
         if (ev_i8) (void)hipEventDestroy(ev_i8);
         if (ev_gate) (void)hipEventDestroy(ev_gate);
         dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes);
-        for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.counters);
+        for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.rowpart); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
@@ -360,13 +370,15 @@ bool use_i8s(const nngp_model* m, int64_t mp) {
     return m->np >= 2048 && mp >= 256 && NNGP_KNOB(5) != 50;
 }
 
-// Two grades of the product.  COARSE: 5 x 5 planes, pairs with ia + ib <= 4 (15 exact plane products; error ~2^-32 sqrt(N) of the row
-// maxima) -- for a FIRST residual.  FINE: 7 x 7 planes, ia + ib <= 6 (28 products; ~2^-48 sqrt(N): what the float64 matrix pipe
+// Two grades of the product.  COARSE: 3 x 5 planes (z ROUNDED to its three and written back, round 4; 5 x 5 before), pairs with
+// ia + ib <= 4 (12 exact plane products, 15 before; error ~2^-32 sqrt(N) of the row maxima, all of it from the kernel's side now)
+// -- for a FIRST residual.  FINE: 7 x 7 planes, ia + ib <= 6 (28 products; ~2^-48 sqrt(N): what the float64 matrix pipe
 // delivers) -- for the later residuals and the NTK's W = Z K_dd, where the coarse floor would show (see residual_rows); 28 products
 // still cost 3/4 of the float64 product at N = 32768.  A model that will ask for FINE products (NTK fits, covariance levels >= 2)
 // has its kernel matrix cut into 7 planes once; coarse products then read the first five of them.
 enum { I8_COARSE = 0, I8_FINE = 1 };
 constexpr int kI8FinePlanes = 7, kI8FineCut = 6;
+constexpr int kI8CoarseZPlanes = 3;  // a first residual's z is rounded to three digits and written back (i8s_product_rows)
 
 // FINE pays later than COARSE (28 against 15 products): from N = 4096 and four 128-row tiles of right-hand sides on.  Debug key 5 = 57: off.
 bool use_i8s_fine(const nngp_model* m, int64_t mp) { return use_i8s(m, mp) && m->np >= 4096 && mp >= 512 && NNGP_KNOB(5) != 57; }
@@ -394,12 +406,13 @@ int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk, int planes) {
     I8Work& w = m->i8;
     if (NNGP_KNOB(5) == 51) { w.ns_k = w.ns_z = 4; w.cut = 3; }
     else if (NNGP_KNOB(5) == 52) { w.ns_k = w.ns_z = 6; w.cut = 5; }
-    else { w.ns_k = w.ns_z = 5; w.cut = 4; }
+    else { w.ns_k = 5; w.ns_z = NNGP_KNOB(5) == 58 ? 5 : kI8CoarseZPlanes; w.cut = 4; }
     if (planes < w.ns_k) planes = w.ns_k;
     w.k_rows = round_up(m->np_cap, 256);
     auto give_up = [&]() -> int {
         dev_free(m->i8.k.planes); dev_free(m->i8.k.scale); dev_free(m->i8.aux.planes); dev_free(m->i8.aux.scale);
-        dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial);
+        dev_free(w.zplanes); dev_free(w.zscale); dev_free(w.partial); dev_free(w.rowpart);
+        w.rowpart_rows = 0;
         m->i8.k.ready = m->i8.aux.ready = false;
         m->i8.k.alloc_planes = m->i8.aux.alloc_planes = 0;
         w.z_rows = 0;
@@ -415,6 +428,13 @@ int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk, int planes) {
         NNGP_HIP_CHECK(hipMemset(pk.planes, 0, (size_t)(planes * w.k_rows * m->np_cap)));
         pk.alloc_planes = planes;
         pk.ready = false;
+    }
+    if (mp > w.rowpart_rows) {
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        dev_free(w.rowpart);
+        w.rowpart_rows = 0;
+        NNGP_TRY(dev_alloc(&w.rowpart, mp * i8s_col_blocks(m->np_cap) * 4));
+        w.rowpart_rows = mp;
     }
     if (w.counters == nullptr) {
         NNGP_TRY(dev_alloc(&w.counters, 16));
@@ -443,7 +463,12 @@ int ensure_i8s(nngp_model* m, int64_t mp, I8Planes& pk, int planes) {
 int i8s_cut_planes(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, hipStream_t s) {
     I8Work& w = m->i8;
     NNGP_TRY(launch_i8s_diag_bound_scale(kmat, kld, m->np, pk.scale, s));
-    NNGP_TRY(launch_i8s_slice_rows(kmat, kld, m->np, m->np, pk.alloc_planes, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
+    // a bitwise symmetric matrix (one symmetric kernel build; the NNGP kernel beside an NTK fit always is): every entry read once
+    const bool sym = (kmat == m->kaux64 || m->k64_symmetric) && (pk.alloc_planes == 5 || pk.alloc_planes == 7) && NNGP_KNOB(5) != 62;
+    if (sym)
+        NNGP_TRY(launch_i8s_slice_sym(kmat, kld, m->np, pk.alloc_planes, pk.scale, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
+    else
+        NNGP_TRY(launch_i8s_slice_rows(kmat, kld, m->np, m->np, pk.alloc_planes, pk.scale, nullptr, pk.planes, m->np_cap, w.k_rows * m->np_cap, s));
     NNGP_TRY(launch_i8s_scale_sqsum(pk.scale, m->np, pk.scale + m->np_cap, s));
     pk.ns_done = pk.alloc_planes;
     pk.ready = true;
@@ -459,9 +484,14 @@ int i8s_cut_planes(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld,
 // small workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on
 // a CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
 int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, double* out, const double* cin, double beta,
-                     double alpha, const double* z, double gamma, int64_t mp, hipStream_t s, int grade) {
+                     double alpha, double* z, double gamma, int64_t mp, hipStream_t s, int grade) {
     const int64_t np = m->np;
     I8Work& w = m->i8;
+    // COARSE: z comes straight from the float32 solves and every identity downstream holds for WHATEVER z they returned -- so z is
+    // rounded to 24-bit fixed point below its row maximum (three planes; the solves' own error is ~1e-4 of it) and written back:
+    // the planes ARE z, planes 3 and 4 do not exist, 12 plane products instead of 15 and no truncation on the z side
+    const bool round_z = grade == I8_COARSE && w.ns_z < w.ns_k;
+    const bool fuse_rows = grade == I8_COARSE && m->i8_fuse_request && cin != nullptr && w.rowpart_rows >= mp && NNGP_KNOB(5) != 59;
     const int ns_z = grade == I8_FINE ? kI8FinePlanes : w.ns_z, ns_k = grade == I8_FINE ? kI8FinePlanes : w.ns_k;
     const int cut = grade == I8_FINE ? kI8FineCut : w.cut;
     NNGP_REQUIRE(pk.alloc_planes >= ns_k && w.z_planes >= ns_z, "i8s_product_rows: workspace for %d planes missing", ns_k);
@@ -473,11 +503,12 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
     if (&pk == &m->i8.k) m->i8_k_pending = false;
     I8Plan pl;
     NNGP_TRY(i8s_plan(ns_z, ns_k, cut, &pl));
-    const int64_t nchunk = i8s_chunks(np);
+    const int64_t nchunk = i8s_chunks(np, &pl);
     for (int64_t r0 = 0; r0 < mp; r0 += kI8RowBlock) {
         const int64_t mb = mp - r0 < kI8RowBlock ? mp - r0 : kI8RowBlock;
         const int64_t slab = mb * np;
-        NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s));
+        NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s,
+                                       round_z ? z + r0 * np : nullptr));
         if (r0 == 0 && grade == I8_COARSE && !m->gate_recorded && NNGP_KNOB(2) != 8 && NNGP_KNOB(2) != 9) {
             // The deferred alpha CG (solve stream) starts HERE, not with the blocked solves before this product: its hundreds of small
             // GEMV launches settle on compute units between the solves' persistent split-float16 launches (which need a whole unit's
@@ -502,9 +533,14 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
             w.t_flops[t] = 2.0 * (double)mb * (double)np * (double)np;
             w.t_ops[t] = w.t_flops[t] * pl.npairs;
         }
+        I8Fuse fuse;
+        fuse.out32 = m->b32 + r0 * np;
+        fuse.ld32 = np;
+        fuse.part = w.rowpart + r0 * i8s_col_blocks(np) * 4;
         NNGP_TRY(launch_i8s_combine(out + r0 * np, np, cin ? cin + r0 * np : nullptr, np, beta, alpha, z + r0 * np, np, gamma, w.partial, np,
-                                    slab, (int)nchunk, pl.ndiag, w.zscale, pk.scale, mb, np, s));
+                                    slab, (int)nchunk, pl.ndiag, w.zscale, pk.scale, mb, np, s, fuse_rows ? &fuse : nullptr));
     }
+    if (fuse_rows) m->i8_fuse_done = true;
     if (grade == I8_COARSE && !m->gate_recorded && NNGP_KNOB(2) == 9) {  // timing experiment: the CG starts when the product has ended
         if (m->ev_gate == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_gate, hipEventDisableTiming));
         NNGP_HIP_CHECK(hipEventRecord(m->ev_gate, s));
@@ -520,7 +556,7 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
 // grade proper -- measured with the coarse product there (scripts/i8s_hard_case.py): NTK variances off by 3e-5 .. 2e-4 (first order
 // in the rows' error) against 1e-8, NNGP level 2 at 1e-7 instead of 1e-8, the explicit inverse of the serving mode stuck four digits
 // short of float64 (serving variances 4e-3 off).  Those take the FINE product where it pays, else the float64 pipe.
-int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z, int64_t mp, hipStream_t s, bool first_residual) {
+int residual_rows(nngp_model* m, double* out, const double* rhs, double* z, int64_t mp, hipStream_t s, bool first_residual) {
     const int64_t np = m->np;
     const bool coarse = first_residual;
     if (!coarse && use_i8s_fine(m, mp)) m->i8_want_fine = true;
@@ -536,6 +572,35 @@ int residual_rows(nngp_model* m, double* out, const double* rhs, const double* z
     return launch_axpby_mat(out, 1.0, z, -m->reg, np, mp, np, s);
 }
 
+// every reader of m->tri calls this on the stream it reads from: builds the inverted blocks there if nobody has yet, else orders the
+// stream behind whoever did
+int tri_join(nngp_model* m, hipStream_t s) {
+    if (m->tri_stale) {
+        if (m->ev_tri == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri, hipEventDisableTiming));
+        NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, s));
+        m->tri_stale = false;
+        m->tri_pending = true;
+        return 0;
+    }
+    if (m->tri_pending) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_tri, 0));
+    return 0;
+}
+
+// predict: the build goes to the panel stream (idle between factorisations) behind what `s` holds now; tri_join orders the readers
+int tri_fork(nngp_model* m, hipStream_t s) {
+    if (!m->tri_stale || m->la == nullptr || m->la->panel == nullptr || NNGP_KNOB(5) == 61) return 0;  // key 5 = 61: in line
+    if (m->ev_tri == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri, hipEventDisableTiming));
+    if (m->ev_tri_fork == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri_fork, hipEventDisableTiming));
+    NNGP_HIP_CHECK(hipEventRecord(m->ev_tri_fork, s));
+    NNGP_HIP_CHECK(hipStreamWaitEvent(m->la->panel, m->ev_tri_fork, 0));
+    NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, m->la->panel));
+    NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, m->la->panel));
+    m->tri_stale = false;
+    m->tri_pending = true;
+    return 0;
+}
+
 // the factor has float16-split copies (look-ahead factorisation) and the caller did not ask for the float32 path
 // and the block of right-hand sides is large enough for the 256-row tiles of the float16 GEMM to pay (measured, ms per
 // diag-variance call at level 2, float16 / float32 solves -- N = 10800: M = 128: 6.5 / 5.6, 512: 9.1 / 8.8, 1024: 11.5 / 12.9;
@@ -547,6 +612,7 @@ bool use_split_solves(const nngp_model* m, int64_t mp) {
 
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
 int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    NNGP_TRY(tri_join(m, s));
     // While the deferred alpha CG runs on its own stream (from the int8 residual's gate on), the solves' persistent update grids
     // leave it some compute units (debug key 13 = n: n units; default 0 = none -- see DESIGN_NOTES R4)
     m->split.solve_reserve = (m->gate_recorded && NNGP_KNOB(13) > 0) ? NNGP_KNOB(13) : 0;
@@ -858,6 +924,7 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
     m->a32_built = false;
     m->a32_complete = false;
     m->k64_partial = false;
+    m->k64_symmetric = a.sym != 0;
     m->i8.k.ready = false;
     m->i8_checked = m->i8_distrusted = false;
     m->i8_guard_pending = false;
@@ -934,6 +1001,7 @@ int nngp_model_factor_input_complete(nngp_model* m) {
 int nngp_model_precond(nngp_model* m, const double* r, double* z, void* stream) {
     NNGP_REQUIRE(m != nullptr && m->factored, "precond: factor first");
     NNGP_REQUIRE(r != nullptr && z != nullptr, "precond: NULL argument");
+    NNGP_TRY(tri_join(m, (hipStream_t)stream));
     return precond_apply(m->a32, m->ld, m->tri, m->n, m->np, r, z, m->pcg, (hipStream_t)stream);
 }
 
@@ -961,7 +1029,8 @@ int nngp_model_factor_end(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->built, "factor_end: build the kernel rows first");
     m->tri.bs = triinv_block(m->np);
-    NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
+    m->tri_stale = true;  // built by the first reader (tri_join), or by a predict beside its cross-kernel build (tri_fork)
+    m->tri_pending = false;
     // the float16-split copy of L by block column, if the factorisation did not leave one behind (recursion at
     // 4096 <= N, block-column ABI of the distributed factorisation): the posterior's solves use it
     if (!m->split.l_ready && m->split.planes != nullptr && m->np >= 4 * m->split.k_cap && m->tri.bs % m->split.k_cap == 0 &&
@@ -1062,17 +1131,21 @@ int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, i
     a.row_begin = n0; a.row_end = n1; a.sym = 0;
     a.ld64 = a.ld32 = m->ld;
     if (m->get == NNGP_GET_NNGP) a.nngp64 = m->k64; else a.ntk64 = m->k64;
+    m->k64_symmetric = false;  // the appended rows' own block is built entry by entry
     NNGP_TRY(launch_kernel_build(a, m->arch, s));
     NNGP_TRY(launch_mirror_rows_f64(m->k64, m->ld, n0, n1, s));
     NNGP_TRY(launch_zero_pad_f64(m->k64, m->ld, n1, np1, s));
     // 3. factor rows [r0, np1)
     NNGP_TRY(launch_factor_input(m->k64, m->ld, m->a32, m->ld, n1, np1, m->reg_fac, m->reg_fac + m->trace_mean, s, r0));
     float* a10 = m->a32 + r0 * m->ld;
+    NNGP_TRY(tri_join(m, s));
     NNGP_TRY(trsm_rlt_blocks_f32(a10, m->ld, rows, m->a32, m->ld, m->tri, r0, m->trsm_tmp, s));
     NNGP_TRY(launch_gemm_nt_f32(a10 + r0, m->ld, a10, m->ld, a10, m->ld, rows, rows, r0, -1.0f, 1.0f, true, s));
     NNGP_TRY(potrf_f32(a10 + r0, rows, m->ld, m->dinv + (r0 / TB) * TB * TB, m->clamped, (float)(0.25 * m->reg_fac), s));
     m->tri.bs = triinv_block(m->np);
-    NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
+    m->tri_stale = true;
+    m->tri_pending = false;
+    NNGP_TRY(tri_join(m, s));  // in order: the old blocks were read just above
     // 4. float16-split copies: rows >= r0 of every block column (same scale as the rest), L^T copies rebuilt lazily
     if (m->split.l_ready && m->split.scale == old_scale && m->split.rows_cap >= np1 + 256) {
         const int64_t bs = m->split.k_cap, ldp = 4 * bs;
@@ -1113,6 +1186,10 @@ static void note_solve(nngp_model* m, int it, double rr) {
 // allow_partial: the caller can correct the mean through the covariance rows, so the CG may stop at kPartialTol.
 static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, bool allow_partial = false) {
     hipStream_t s = m->solve_stream;
+    auto join_tri = [&]() -> int {  // the preconditioner's inverted blocks: behind the factor (ev_ready), built here if nobody has yet
+        NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_ready, 0));
+        return tri_join(m, s);
+    };
     if (!m->solve_pending) {
         if (!m->cg_partial || allow_partial) {
             // alpha was written on the solve stream: a caller on another stream than the one that triggered the solve
@@ -1125,6 +1202,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
         if (m->have_predict_event) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_predict, 0));
         int it = 0;
         double rr = 0.0;
+        NNGP_TRY(join_tri());
         NNGP_TRY(pcg_finish(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.xcol, m->pcg, m->cg_iters_done,
                             m->pend_max_iters, m->pend_tol, &it, &rr, s, true));
         NNGP_TRY(launch_strided_copy_f64(m->pcg.xcol, 1, m->alpha, m->ny, m->n, s));
@@ -1144,6 +1222,7 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
     m->cg_partial = false;
     const bool partial = allow_partial && m->ny == 1 && m->pend_tol < 1e-3 && NNGP_KNOB(0) != 128;
     const double tol = partial ? ((NNGP_KNOB(3) >= 41 && NNGP_KNOB(3) <= 52) ? pow(10.0, -(double)(NNGP_KNOB(3) - 40)) : kPartialTol) : m->pend_tol;
+    NNGP_TRY(join_tri());
     if (m->solve_ahead > 0) {
         const int ahead = m->solve_ahead;
         m->solve_ahead = 0;
@@ -1198,6 +1277,7 @@ int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream)
     if (m->ny == 1 && NNGP_KNOB(0) == 64) {
         const int ahead = m->pend_max_iters < kSolveAhead ? m->pend_max_iters : kSolveAhead;
         NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_ready, 0));
+        NNGP_TRY(tri_join(m, m->solve_stream));
         NNGP_TRY(launch_strided_copy_f64(m->y, 1, m->pcg.bcol, 1, m->n, m->solve_stream));
         NNGP_TRY(pcg_begin(m->k64, m->ld, m->n, m->reg, m->a32, m->ld, m->tri, m->np, m->pcg.bcol, m->pcg.xcol, m->pcg, ahead,
                            m->solve_stream));
@@ -1373,8 +1453,18 @@ int nngp_model_prepare_serving(nngp_model* m, void* stream) {
     return 0;
 }
 
+static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode, double* mean, double* var_or_cov, void* stream);
+
 int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode, double* mean,
                        double* var_or_cov, void* stream) {
+    const int rc = predict_impl(m, x_test, mt, cov_mode, mean, var_or_cov, stream);
+    // whatever path the predict took, the caller's stream leaves behind the build of the inverted blocks it may have forked (tri_fork)
+    if (m != nullptr && !m->tri_stale && m->tri_pending) (void)hipStreamWaitEvent((hipStream_t)stream, m->ev_tri, 0);
+    return rc;
+}
+
+static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t cov_mode, double* mean, double* var_or_cov,
+                        void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->solved, "predict: fit the model first");
     NNGP_REQUIRE(cov_mode >= NNGP_COV_NONE && cov_mode <= NNGP_COV_FULL, "predict: bad cov_mode");
@@ -1387,6 +1477,7 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
     const int64_t n = m->n, np = m->np, mp = round_up(mt, TB);
     const bool compact_train = on_train && m->ld != m->np;  // K_dd rows have stride ld: copy them to the compact cross buffer
     NNGP_TRY(ensure_predict_capacity(m, mt, !on_train || compact_train));
+    NNGP_TRY(tri_fork(m, s));  // first predict of a fit: the factor's inverted blocks are built beside the cross-kernel build
 
     // ---- cross kernel of `get` and the mean: mu = K_td alpha (float64) ----
     const double* xt = on_train ? m->x : x_test;
@@ -1519,12 +1610,21 @@ int nngp_model_predict(nngp_model* m, const double* x_test, int64_t mt, int32_t 
             // correction term (<~ 1e-2 of the variance) depends on it.  Measured at N = 32768 against level 4: 2.1e-6 worst
             // relative error (level 2: 4.2e-7 for one more solve pair and half a float64 product; the formula without the
             // last term, z0.(k + r0) via the quadratic form alone: 4.7e-3 -- e0^T A e0 is NOT negligible).
-            NNGP_TRY(solve_rows(0, true));
+            // (an int8 residual's combination pass also leaves z.(k + r0), z.r0, the statistics of z and float32(r0): I8Fuse)
+            m->i8_fuse_request = true;
+            m->i8_fuse_done = false;
+            const int rc_solve = solve_rows(0, true);
+            m->i8_fuse_request = false;
+            NNGP_TRY(rc_solve);
             z_valid = true;
-            NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
-            NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s,
-                                       m->i8_used_now ? m->rows.zstat : nullptr));
-            NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
+            if (m->i8_fuse_done) {
+                NNGP_TRY(launch_i8s_rowstat_finish(m->i8.rowpart, np, mt, m->tt_diag, var_or_cov, m->rows.delta, m->rows.zstat, s));
+            } else {
+                NNGP_TRY(launch_rowdot_f64(m->z64, ktd, 1.0, m->r64, np, mt, np, m->tt_diag, -1.0, var_or_cov, s));
+                NNGP_TRY(launch_rowdot_f64(m->z64, nullptr, 0.0, m->r64, np, mt, np, nullptr, 1.0, m->rows.delta, s,
+                                           m->i8_used_now ? m->rows.zstat : nullptr));
+                NNGP_TRY(launch_convert_f64_f32(m->r64, np, m->b32, np, mp, np, mp, np, s));
+            }
             NNGP_TRY(apply_forward_f32(m, mp, s));
             NNGP_TRY(launch_row_sqsum_f32(m->b32, np, mt, np, var_or_cov, var_or_cov, s));
             check_kind = 4;  // like 1, and r64 already holds the residual of z64
@@ -1842,7 +1942,7 @@ int nngp_gemm_nt_i8s(double* c, int64_t ldc, const double* cin, int64_t ldcin, c
     I8Plan pl;
     NNGP_TRY(i8s_plan(slices_a, slices_b, cut, &pl));
     const int64_t mp = round_up(m, 256), np = round_up(n, 256), kp = round_up(k, 128);
-    const int64_t nchunk = i8s_chunks(k);
+    const int64_t nchunk = i8s_chunks(k, &pl);
     const int64_t slab = m * n;
     const size_t plane_bytes = (size_t)((mp * slices_a + np * slices_b) * kp);
     const size_t part_bytes = (size_t)(nchunk * pl.ndiag * slab) * sizeof(int32_t);

@@ -34,6 +34,9 @@ void set_error(const char* fmt, ...);
 //   7  1 = 128-wide recursion in the posterior solves; any non-zero value = float32 solve path; 3 = CG solve in stream
 //      order instead of deferred
 //   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
+//   5  (also) 50..57 int8 residual path (api.hip: use_i8s, ensure_i8s); round 4: 58 = five digit planes of z instead of three rounded ones;
+//      59 = row statistics and float32 copy in passes of their own instead of the fused combination; 60 = K chunks of 16384 always;
+//      61 = the factor's inverted blocks built in line (not beside the first predict's cross-kernel build); 62 = digit planes of K row by row
 //   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
 //   8  round 4, grouped Cholesky (set BEFORE the model is created): bit 1 = the schedule with the panel solves off the update stream
 //      (potrf_lookahead_grouped_v4; needs its extra streams); with it: 2 = bulk panel solves on the panel stream itself; 4 = early part
@@ -246,6 +249,8 @@ struct I8Work {       // one per model (api.hip): planes of K (and of the NNGP k
     int64_t z_rows = 0;
     int z_planes = 0;            // planes zplanes / partial have room for
     int32_t* partial = nullptr;  // [chunks][diagonals][z_rows][np_cap] exact plane products
+    double* rowpart = nullptr;   // [rowpart_rows][np_cap / 1024][4] partial row statistics of the fused combination (I8Fuse)
+    int64_t rowpart_rows = 0;
     int* counters = nullptr;     // work counters of the persistent grid
     int ns_k = 5, ns_z = 5, cut = 4;
     // live timing of the plane-product launches since the timer was last read (nngp_model_residual_timer_read)
@@ -257,7 +262,8 @@ struct I8Work {       // one per model (api.hip): planes of K (and of the NNGP k
     double t_flops[kMaxTimed] = {}; // algorithmic: the float64 product they stand for, 2 m n k
 };
 int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl);
-int64_t i8s_chunks(int64_t k);  // K chunks (of <= 16384) a product over k columns is cut into
+int64_t i8s_chunks(int64_t k, const I8Plan* pl = nullptr);  // K chunks a product over k columns is cut into: of <= 16384, or <= 40960 when no diagonal
+                                                                // of the plan has more than 3 pairs (int32 accumulators); without a plan: the larger count
 int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double* scale, hipStream_t s);
 int launch_i8s_scale_sqsum(const double* scale, int64_t n, double* out, hipStream_t s);
 int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t cols, const double* var, const I8Plan& pl, int nsa, int nsb,
@@ -266,13 +272,24 @@ int launch_i8s_floor_ratio(const double* z, int64_t ld, int64_t rows, int64_t co
 int launch_i8s_floor_ratio_rows(const double* zstat, int64_t rows, const double* var, const I8Plan& pl, int nsa, int nsb, const double* sk2,
                                 unsigned long long* out, hipStream_t s);
 int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t cols, int ns, const double* scale_in, double* scale_out,
-                          int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s);  // scale_in NULL: scale by the row maxima
+                          int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s, double* writeback = nullptr);  // scale_in NULL: scale by the row maxima
+int launch_i8s_slice_sym(const double* src, int64_t ld, int64_t n, int ns, const double* scale, int8_t* planes, int64_t ldp,
+                         int64_t pstride, hipStream_t s);  // all planes of a bitwise symmetric matrix, every entry read once
 int launch_gemm_nt_i8s(int32_t* partial, int64_t ldc, int64_t slab, const int8_t* a, int64_t lda, int64_t sa, const int8_t* b,
                        int64_t ldb, int64_t sb, const I8Plan& pl, int64_t m, int64_t n, int64_t k, int* counters, int reserve_cus,
                        hipStream_t s);
+struct I8Fuse {           // what the combination pass of a level-1 residual also delivers (k_i8s_combine<true>)
+    float* out32 = nullptr;   // float32 copy of the result, [rows, ld32]
+    int64_t ld32 = 0;
+    double* part = nullptr;   // [rows][i8s_col_blocks(cols)][4] partial row statistics, summed by launch_i8s_rowstat_finish
+};
+int64_t i8s_col_blocks(int64_t cols);
 int launch_i8s_combine(double* out, int64_t ldo, const double* cin, int64_t ldcin, double beta, double alpha, const double* g,
                        int64_t ldg, double gamma, const int32_t* partial, int64_t ldc, int64_t slab, int nchunk, int ndiag,
-                       const double* sa, const double* sb, int64_t rows, int64_t cols, hipStream_t s);
+                       const double* sa, const double* sb, int64_t rows, int64_t cols, hipStream_t s, const I8Fuse* fuse = nullptr);
+// var = base - sum z.(k + r), delta = sum z.r, zstat = (|z|^2, max |z|) per row from the partial statistics of the fused combination
+int launch_i8s_rowstat_finish(const double* part, int64_t cols, int64_t rows, const double* base, double* var, double* delta,
+                              double* zstat, hipStream_t s);
 
 // ---- gemm_f64.hip ----
 int launch_gemm_nt_f64(double* c, int64_t ldc, const double* cin, int64_t ldcin, const double* a, int64_t lda,

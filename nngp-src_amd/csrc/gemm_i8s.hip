@@ -7,7 +7,7 @@
 // and only the pairs with i + j <= cut are formed: the dropped ones are below 256^-(cut+3) 2^14 ~ 2^-42 (cut = 4) of the row scales
 // per k.  Two grades are used (api.hip): 5 x 5 planes with cut 4 (15 products) and 7 x 7 with cut 6 (28: float64 grade proper).
 // All pairs of one "diagonal" i + j = e share a weight and ONE int32 accumulator; K is cut into chunks of <= 16384 so that no
-// accumulator can overflow (7 pairs x 16384 k x 2^14 < 2^31).  A second kernel adds the diagonals in float64 (Horner in 2^-8,
+// accumulator can overflow (7 pairs x 16384 k x 2^14 < 2^31; <= 40960 when no diagonal has more than 3 pairs: round 4).  A second kernel adds the diagonals in float64 (Horner in 2^-8,
 // fixed order: bitwise reproducible), applies the row scales and fuses beta*Cin and gamma*G.
 //
 // Why: the posterior's residual product R = K_td - Z (K + reg I) (reference: predict_fn(..., compute_cov=True),
@@ -38,7 +38,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int IT = 256;               // workgroup tile (rows and columns)
 constexpr int IROW = 128;             // bytes per LDS row: 128 k of one plane
 constexpr int ISTAGE = 2 * IT * IROW; // A rows + B rows: 64 KB
-constexpr int kI8ChunkBlocks = 128;   // k-blocks (of 128) per K chunk: 16384 k
+constexpr int kI8ChunkBlocks = 128;   // k-blocks (of 128) per K chunk: 16384 k (up to 7 pairs on a diagonal)
+constexpr int kI8ChunkBlocks3 = 320;  // ... when no diagonal has more than 3 pairs: 3 x 40960 k x 2^14 = 2.01e9 < 2^31
 
 // ---- row scales ----
 // A power of two (integers stay exact, and the scaling itself never rounds): with max|row| = f 2^e, f in [0.5, 1), scale = 2^(e+1)
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(1024) void k_i8s_diag_bound_scale(const double* __r
 // loads, digits through LDS, 16-byte stores per plane (the second pass over the row is served by the L2 / MALL).
 // planes[p][r][c] at planes + p * pstride + r * ldp + c; columns [cols, kp) are written as zero.
 template <int NS>
-__global__ __launch_bounds__(256) void k_i8s_slice_rows(const double* __restrict__ src, int64_t ld, int64_t cols, int64_t kp,
+__global__ __launch_bounds__(256) void k_i8s_slice_rows(const double* src, int64_t ld, int64_t cols, int64_t kp,
                                                         const double* __restrict__ scale_in, double* __restrict__ scale_out,
-                                                        int8_t* __restrict__ planes, int64_t ldp, int64_t pstride) {
+                                                        int8_t* __restrict__ planes, int64_t ldp, int64_t pstride, double* wb) {
     __shared__ __attribute__((aligned(16))) unsigned char dig[NS][4096];
     __shared__ double red[4];
     const int t = threadIdx.x;
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(256) void k_i8s_slice_rows(const double* __restrict
         if (t == 0) scale_out[r] = scale;
     }
     const double inv = ldexp(1.0, 8 * NS) / scale;
+    const double back = scale * ldexp(1.0, -8 * NS);  // scale is a power of two: x * back is the value the planes hold, exactly
+    double* q = wb != nullptr ? wb + r * ld : nullptr;
     for (int64_t seg0 = 0; seg0 < kp; seg0 += 4096) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -115,6 +118,13 @@ __global__ __launch_bounds__(256) void k_i8s_slice_rows(const double* __restrict
                 v[0] = p[c];
             }
             long long x0 = __double2ll_rn(v[0] * inv), x1 = __double2ll_rn(v[1] * inv);
+            if (q != nullptr) {  // the caller goes on with the ROUNDED row: its planes are then the row itself, not an approximation
+                if (c + 1 < cols) {
+                    *reinterpret_cast<f64x2*>(q + c) = f64x2{(double)x0 * back, (double)x1 * back};
+                } else if (c < cols) {
+                    q[c] = (double)x0 * back;
+                }
+            }
 #pragma unroll
             for (int s = NS - 1; s >= 1; --s) {  // least significant digit first; plane 0 = most significant
                 const long long d0 = ((x0 + 128) & 255) - 128, d1 = ((x1 + 128) & 255) - 128;
@@ -133,6 +143,78 @@ __global__ __launch_bounds__(256) void k_i8s_slice_rows(const double* __restrict
                 *reinterpret_cast<i32x4*>(planes + s * pstride + r * ldp + c16) = *reinterpret_cast<const i32x4*>(&dig[s][16 * t]);
         }
         __syncthreads();
+    }
+}
+
+// ---- the same planes of a bitwise SYMMETRIC matrix, every entry read once (round 4) ----
+// One workgroup per 128 x 128 tile (I, J) of the lower triangle: the tile goes to LDS, is cut with its rows' scales into the planes'
+// rows 128 I.., columns 128 J.. and -- off the diagonal -- transposed with its columns' scales into rows 128 J.., columns 128 I..:
+// 8 N^2 / 2 bytes read instead of 8 N^2 for the same NS N^2 written, in 128-byte plane lines.  Same digits as k_i8s_slice_rows (the
+// same rounding of the same product), so the planes are bit-identical when src is.  n: multiple of 128 (padding rows / columns hold zeros).
+constexpr int kSymT = 128, kSymLd = kSymT + 1;
+template <int NS>
+__device__ __forceinline__ void i8s_digits16(const double* v, int stride, double inv, i32x4* dig) {
+    unsigned char b[NS][16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        long long x = __double2ll_rn(v[c * stride] * inv);
+#pragma unroll
+        for (int s = NS - 1; s >= 1; --s) {
+            const long long d = ((x + 128) & 255) - 128;
+            x = (x - d) >> 8;
+            b[s][c] = (unsigned char)(d & 255);
+        }
+        b[0][c] = (unsigned char)(x & 255);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        i32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            w[q] = (int)((unsigned)b[s][4 * q] | ((unsigned)b[s][4 * q + 1] << 8) | ((unsigned)b[s][4 * q + 2] << 16) | ((unsigned)b[s][4 * q + 3] << 24));
+        dig[s] = w;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_i8s_slice_sym(const double* __restrict__ src, int64_t ld, const double* __restrict__ scale,
+                                                       int8_t* __restrict__ planes, int64_t ldp, int64_t pstride) {
+    __shared__ double tile[kSymT * kSymLd];  // 132 KB: one workgroup per compute unit
+    const int t = threadIdx.x;
+    // lower-triangle tile (I, J), I >= J, from the linear index
+    const long long b = blockIdx.x;
+    long long I = (long long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= b) ++I;
+    while (I * (I + 1) / 2 > b) --I;
+    const long long J = b - I * (I + 1) / 2;
+    const double* p = src + (I * kSymT) * ld + J * kSymT;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int row = 4 * i + (t >> 6), col = 2 * (t & 63);
+        const f64x2 v = *reinterpret_cast<const f64x2*>(p + (int64_t)row * ld + col);
+        tile[row * kSymLd + col] = v[0];
+        tile[row * kSymLd + col + 1] = v[1];
+    }
+    __syncthreads();
+    const double top = ldexp(1.0, 8 * NS);
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {  // rows of the tile with their own scales
+        const int item = it * 256 + t, row = item >> 3, g = item & 7;
+        const int64_t r = I * kSymT + row;
+        i32x4 dig[NS];
+        i8s_digits16<NS>(tile + row * kSymLd + 16 * g, 1, top / scale[r], dig);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<i32x4*>(planes + s * pstride + r * ldp + J * kSymT + 16 * g) = dig[s];
+    }
+    if (I == J) return;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {  // its columns = rows 128 J.. of the matrix, with their scales
+        const int item = it * 256 + t, col = item >> 3, g = item & 7;
+        const int64_t r = J * kSymT + col;
+        i32x4 dig[NS];
+        i8s_digits16<NS>(tile + (16 * g) * kSymLd + col, kSymLd, top / scale[r], dig);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<i32x4*>(planes + s * pstride + r * ldp + I * kSymT + 16 * g) = dig[s];
     }
 }
 
@@ -396,34 +478,88 @@ __global__ __launch_bounds__(512) void k_gemm_nt_i8s(int* P, int64_t ldc, int64_
 // ---- float64 combination of the diagonals ----
 // out = beta cin + alpha sa[r] sb[c] 2^-16 sum_dd 2^(-8 e_dd) sum_ch P[ch][dd] + gamma g,   e_dd = ndiag - 1 - dd (largest first).
 // One thread per 4 columns; Horner from the least significant diagonal.
+// FUSE (the level-1 variance, api.hip): the pass also writes the float32 copy of the result (right-hand side of the remainder solve) and,
+// per row and block of 1024 columns, the partial sums of g.(cin + out), g.out, g.g and max |g| -- g = z, cin = k, out = the residual r:
+// what two row-dot passes and a conversion pass over [rows, cols] delivered before.  k_i8s_rowstat_finish adds the blocks in order.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_i8s_combine(double* __restrict__ out, int64_t ldo, const double* __restrict__ cin, int64_t ldcin,
                                                      double beta, double alpha, const double* __restrict__ g, int64_t ldg, double gamma,
                                                      const int* __restrict__ P, int64_t ldc, int64_t slab, int nchunk, int ndiag,
                                                      const double* __restrict__ sa, const double* __restrict__ sb, int64_t rows,
-                                                     int64_t cols) {
+                                                     int64_t cols, float* __restrict__ out32, int64_t ld32, double* __restrict__ part) {
     const int64_t c4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int64_t r = blockIdx.y;
-    if (c4 >= cols || r >= rows) return;
-    double t[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int dd = 0; dd < ndiag; ++dd) {
-        long long sum[4] = {0, 0, 0, 0};
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const i32x4 v = *reinterpret_cast<const i32x4*>(P + ((int64_t)ch * ndiag + dd) * slab + r * ldc + c4);
+    const bool live = c4 < cols && r < rows;
+    if (!FUSE && !live) return;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0;
+    if (live) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int dd = 0; dd < ndiag; ++dd) {
+            long long sum[4] = {0, 0, 0, 0};
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const i32x4 v = *reinterpret_cast<const i32x4*>(P + ((int64_t)ch * ndiag + dd) * slab + r * ldc + c4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+                for (int e = 0; e < 4; ++e) sum[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = t[e] * 0.00390625 + (double)sum[e];
         }
+        const double w = alpha * sa[r] * (1.0 / 65536.0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = t[e] * 0.00390625 + (double)sum[e];
+        for (int e = 0; e < 4; ++e) {
+            if (c4 + e >= cols) break;
+            double v = w * sb[c4 + e] * t[e];
+            const double cv = (beta != 0.0 || FUSE) ? cin[r * ldcin + c4 + e] : 0.0;
+            const double gv = (gamma != 0.0 || FUSE) ? g[r * ldg + c4 + e] : 0.0;
+            if (beta != 0.0) v += beta * cv;
+            if (gamma != 0.0) v += gamma * gv;
+            out[r * ldo + c4 + e] = v;
+            if (FUSE) {
+                out32[r * ld32 + c4 + e] = (float)v;
+                s1 = fma(gv, cv + v, s1);
+                s2 = fma(gv, v, s2);
+                s3 = fma(gv, gv, s3);
+                mx = fmax(mx, fabs(gv));
+            }
+        }
     }
-    const double w = alpha * sa[r] * (1.0 / 65536.0);
+    if (FUSE) {
+        __shared__ double red[16];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (c4 + e >= cols) break;
-        double v = w * sb[c4 + e] * t[e];
-        if (beta != 0.0) v += beta * cin[r * ldcin + c4 + e];
-        if (gamma != 0.0) v += gamma * g[r * ldg + c4 + e];
-        out[r * ldo + c4 + e] = v;
+        for (int off = 32; off > 0; off >>= 1) {
+            s1 += __shfl_down(s1, off);
+            s2 += __shfl_down(s2, off);
+            s3 += __shfl_down(s3, off);
+            mx = fmax(mx, __shfl_down(mx, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            red[w] = s1; red[4 + w] = s2; red[8 + w] = s3; red[12 + w] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 && r < rows) {
+            const int q = threadIdx.x;
+            const double v = q < 3 ? (red[4 * q] + red[4 * q + 1]) + (red[4 * q + 2] + red[4 * q + 3])
+                                   : fmax(fmax(red[12], red[13]), fmax(red[14], red[15]));
+            part[(r * gridDim.x + blockIdx.x) * 4 + q] = v;
+        }
     }
+}
+
+// var[r] = base[r] - sum_b part[r][b][0], delta[r] = sum_b part[r][b][1], zstat[2 r] = sum_b part[r][b][2], zstat[2 r + 1] = max_b part[r][b][3]
+__global__ void k_i8s_rowstat_finish(const double* __restrict__ part, int nblk, int64_t rows, const double* __restrict__ base,
+                                     double* __restrict__ var, double* __restrict__ delta, double* __restrict__ zstat) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const double* p = part + (r * nblk + b) * 4;
+        s1 += p[0]; s2 += p[1]; s3 += p[2]; mx = fmax(mx, p[3]);
+    }
+    var[r] = base[r] - s1;
+    delta[r] = s2;
+    zstat[2 * r] = s3;
+    zstat[2 * r + 1] = mx;
 }
 
 
@@ -495,9 +631,10 @@ int launch_i8s_diag_bound_scale(const double* src, int64_t ld, int64_t n, double
     return 0;
 }
 
-// scale_in == nullptr: every row is scaled by its own maximum, written to scale_out; otherwise scale_in[r] >= max|row r| * 256/126, a power of two
+// scale_in == nullptr: every row is scaled by its own maximum, written to scale_out; otherwise scale_in[r] >= max|row r| * 256/126, a power of two.
+// writeback (may be src itself): receives every row ROUNDED to its ns digits -- the planes then hold that row exactly
 int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t cols, int ns, const double* scale_in, double* scale_out,
-                          int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s) {
+                          int8_t* planes, int64_t ldp, int64_t pstride, hipStream_t s, double* writeback) {
     if (rows <= 0) return 0;
     const int64_t kp = round_up(cols, 128);
     NNGP_REQUIRE(ns >= 2 && ns <= 7 && ld % 2 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 15) == 0 && ldp >= kp &&
@@ -505,13 +642,29 @@ int launch_i8s_slice_rows(const double* src, int64_t ld, int64_t rows, int64_t c
                  "i8s_slice_rows: 2..7 planes, 16-byte aligned operands");
     const dim3 g((unsigned)rows);
     switch (ns) {
-        case 2: hipLaunchKernelGGL(k_i8s_slice_rows<2>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
-        case 3: hipLaunchKernelGGL(k_i8s_slice_rows<3>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
-        case 4: hipLaunchKernelGGL(k_i8s_slice_rows<4>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
-        case 5: hipLaunchKernelGGL(k_i8s_slice_rows<5>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
-        case 6: hipLaunchKernelGGL(k_i8s_slice_rows<6>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
-        default: hipLaunchKernelGGL(k_i8s_slice_rows<7>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride); break;
+        case 2: hipLaunchKernelGGL(k_i8s_slice_rows<2>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride, writeback); break;
+        case 3: hipLaunchKernelGGL(k_i8s_slice_rows<3>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride, writeback); break;
+        case 4: hipLaunchKernelGGL(k_i8s_slice_rows<4>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride, writeback); break;
+        case 5: hipLaunchKernelGGL(k_i8s_slice_rows<5>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride, writeback); break;
+        case 6: hipLaunchKernelGGL(k_i8s_slice_rows<6>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride, writeback); break;
+        default: hipLaunchKernelGGL(k_i8s_slice_rows<7>, g, dim3(256), 0, s, src, ld, cols, kp, scale_in, scale_out, planes, ldp, pstride, writeback); break;
     }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// planes of a bitwise symmetric [n, n] matrix (n a multiple of 128; rows and columns beyond the data hold zeros) with the given row
+// scales: every entry is read once (k_i8s_slice_sym).  5 or 7 planes.
+int launch_i8s_slice_sym(const double* src, int64_t ld, int64_t n, int ns, const double* scale, int8_t* planes, int64_t ldp,
+                         int64_t pstride, hipStream_t s) {
+    if (n <= 0) return 0;
+    NNGP_REQUIRE((ns == 5 || ns == 7) && n % kSymT == 0 && ld % 2 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 15) == 0 &&
+                     ldp >= n && ldp % 16 == 0 && pstride % 16 == 0 && scale != nullptr,
+                 "i8s_slice_sym: 5 or 7 planes of a matrix padded to 128");
+    const int64_t tn = n / kSymT, tiles = tn * (tn + 1) / 2;
+    NNGP_REQUIRE(tiles < 2147483647LL, "i8s_slice_sym: too many tiles");
+    if (ns == 5) hipLaunchKernelGGL(k_i8s_slice_sym<5>, dim3((unsigned)tiles), dim3(256), 0, s, src, ld, scale, planes, ldp, pstride);
+    else hipLaunchKernelGGL(k_i8s_slice_sym<7>, dim3((unsigned)tiles), dim3(256), 0, s, src, ld, scale, planes, ldp, pstride);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -580,9 +733,16 @@ int i8s_plan(int nsa, int nsb, int cut, I8Plan* pl) {
     return 0;
 }
 
-int64_t i8s_chunks(int64_t k) {
-    const int64_t nkb = (k + 127) / 128;
-    return (nkb + kI8ChunkBlocks - 1) / kI8ChunkBlocks;
+static int chunk_blocks(const I8Plan* pl) {
+    if (pl == nullptr || NNGP_KNOB(5) == 60) return kI8ChunkBlocks;  // key 5 = 60: timing experiment, short chunks always
+    int most = 0;
+    for (int d = 0; d < pl->ndiag; ++d) most = pl->dstart[d + 1] - pl->dstart[d] > most ? pl->dstart[d + 1] - pl->dstart[d] : most;
+    return most <= 3 ? kI8ChunkBlocks3 : kI8ChunkBlocks;
+}
+
+int64_t i8s_chunks(int64_t k, const I8Plan* pl) {
+    const int64_t nkb = (k + 127) / 128, cb = chunk_blocks(pl);
+    return (nkb + cb - 1) / cb;
 }
 
 // a [m rows, ns planes], b [n rows]: int8 planes with row strides lda / ldb bytes (multiples of 128 bytes holding >= round_up(k, 128)
@@ -600,7 +760,7 @@ int launch_gemm_nt_i8s(int32_t* partial, int64_t ldc, int64_t slab, const int8_t
                      ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && counters != nullptr && 8 * lda < (1LL << 31) &&
                      8 * ldb < (1LL << 31) && 16 * ldc * 4 < (1LL << 31),
                  "gemm_nt_i8s: operand planes must be 16-byte aligned with row strides that are multiples of 128");
-    const int64_t nchunk = (nkb + kI8ChunkBlocks - 1) / kI8ChunkBlocks;
+    const int64_t nchunk = i8s_chunks(k, &pl);
     const int64_t kcb = (nkb + nchunk - 1) / nchunk;
     unsigned long long pa_lo = 0, pa_hi = 0, pb_lo = 0, pb_hi = 0, ds_lo = 0;
     unsigned ds_hi = 0;
@@ -639,15 +799,35 @@ int launch_gemm_nt_i8s(int32_t* partial, int64_t ldc, int64_t slab, const int8_t
 
 int launch_i8s_combine(double* out, int64_t ldo, const double* cin, int64_t ldcin, double beta, double alpha, const double* g,
                        int64_t ldg, double gamma, const int32_t* partial, int64_t ldc, int64_t slab, int nchunk, int ndiag,
-                       const double* sa, const double* sb, int64_t rows, int64_t cols, hipStream_t s) {
+                       const double* sa, const double* sb, int64_t rows, int64_t cols, hipStream_t s, const I8Fuse* fuse) {
     if (rows <= 0 || cols <= 0) return 0;
     NNGP_REQUIRE((beta == 0.0 || cin != nullptr) && (gamma == 0.0 || g != nullptr) && ldc % 4 == 0, "i8s_combine: NULL input");
+    NNGP_REQUIRE(fuse == nullptr || (cin != nullptr && g != nullptr && fuse->out32 != nullptr && fuse->part != nullptr && fuse->ld32 >= cols),
+                 "i8s_combine: the fused row statistics need both addends");
+    const unsigned nbx = (unsigned)i8s_col_blocks(cols);
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        hipLaunchKernelGGL(k_i8s_combine, dim3((unsigned)((cols + 1023) / 1024), (unsigned)nr), dim3(256), 0, s, out + r0 * ldo, ldo,
-                           cin ? cin + r0 * ldcin : nullptr, ldcin, beta, alpha, g ? g + r0 * ldg : nullptr, ldg, gamma,
-                           partial + r0 * ldc, ldc, slab, nchunk, ndiag, sa + r0, sb, nr, cols);
+        if (fuse != nullptr)
+            hipLaunchKernelGGL(k_i8s_combine<true>, dim3(nbx, (unsigned)nr), dim3(256), 0, s, out + r0 * ldo, ldo, cin + r0 * ldcin, ldcin,
+                               beta, alpha, g + r0 * ldg, ldg, gamma, partial + r0 * ldc, ldc, slab, nchunk, ndiag, sa + r0, sb, nr, cols,
+                               fuse->out32 + r0 * fuse->ld32, fuse->ld32, fuse->part + r0 * nbx * 4);
+        else
+            hipLaunchKernelGGL(k_i8s_combine<false>, dim3(nbx, (unsigned)nr), dim3(256), 0, s, out + r0 * ldo, ldo,
+                               cin ? cin + r0 * ldcin : nullptr, ldcin, beta, alpha, g ? g + r0 * ldg : nullptr, ldg, gamma,
+                               partial + r0 * ldc, ldc, slab, nchunk, ndiag, sa + r0, sb, nr, cols, (float*)nullptr, (int64_t)0,
+                               (double*)nullptr);
     }
+    NNGP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int64_t i8s_col_blocks(int64_t cols) { return (cols + 1023) / 1024; }
+
+int launch_i8s_rowstat_finish(const double* part, int64_t cols, int64_t rows, const double* base, double* var, double* delta,
+                              double* zstat, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_i8s_rowstat_finish, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, (int)i8s_col_blocks(cols), rows,
+                       base, var, delta, zstat);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }

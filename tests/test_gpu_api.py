@@ -515,6 +515,30 @@ def test_pool_select_on_the_device_matches_the_host_build(golden_dir):
     model.close()
 
 
+@pytest.mark.parametrize("get,n,mt", [("nngp", 2600, 300), ("ntk", 4200, 520)])
+def test_digit_planes_cut_from_the_lower_triangle_are_the_row_cut_bit_for_bit(get, n, mt):
+    """Round 4: the digit planes of the kernel matrix (operand of the posterior's int8 residual product; reference op: the
+    covariance of predict_fn, train.py:157-158) are cut from the lower triangle of the bitwise symmetric kernel buffer, every entry
+    read once (k_i8s_slice_sym: 128 x 128 tiles, direct with the rows' scales and transposed with the columns').  Same digits as the
+    row-by-row cut (timing-knob key 5 = 62): every number downstream is bit-identical -- 5 planes (NNGP) and 7 planes + the NNGP
+    kernel beside an NTK fit."""
+    x, y = synth.synthetic_queries(n, 24, seed=51)
+    xt, _ = synth.synthetic_queries(mt, 24, seed=52)
+    model = GPModel(n, 24, [1.0, 1.1], [0.0, 0.1], get=get, diag_reg=1e-3, knobs=True)
+    outs = []
+    for key in (0, 62):
+        model.debug_set(5, key)
+        model.fit(x, y)
+        model.residual_timer(True)
+        mean, var = model.predict(xt, cov="diag")
+        assert model.residual_timer_read()[0] >= 1   # the int8 path ran
+        outs.append((np.asarray(mean), np.asarray(var)))
+    model.debug_set(5, 0)
+    model.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_int8_residual_path_against_the_float64_residual():
     """The level-1 variance with its residual product on the int8 pipe (exact digit planes, gemm_i8s.hip; reference op: the
     covariance of predict_fn(..., compute_cov=True), train.py:157-158) against the same predict with the float64 product
@@ -526,7 +550,7 @@ def test_int8_residual_path_against_the_float64_residual():
     model.residual_timer(True)
     mean_i8, var_i8 = model.predict(xt, cov="diag")
     launches, ms, flops, ops = model.residual_timer_read()
-    assert launches == 1 and ops == 15 * flops and flops == 2.0 * 384 * 2688 * 2688 and ms > 0.0
+    assert launches == 1 and ops == 12 * flops and flops == 2.0 * 384 * 2688 * 2688 and ms > 0.0  # 3 x 5 planes, i + j <= 4: 12 pairs
     ratio, distrusted = model.residual_floor()   # the guard's estimate of what the dropped digit pairs cost these variances
     assert 0.0 < ratio < 1e-5 and not distrusted, ratio
     model.predict(xt[:100], cov="diag")
@@ -535,7 +559,8 @@ def test_int8_residual_path_against_the_float64_residual():
     mean_64, var_64 = model.predict(xt, cov="diag")
     assert model.residual_timer_read()[0] == 0
     model.debug_set(5, 0)
-    np.testing.assert_array_equal(mean_i8, mean_64)  # the mean does not pass through the residual
+    # the mean passes through Z only in its early-stop correction Z r_alpha, and the int8 path goes on with Z rounded to 24 bits
+    assert np.max(np.abs(mean_i8 - mean_64)) <= 1e-10 * np.max(np.abs(mean_64))
     assert np.max(np.abs(var_i8 - var_64) / np.abs(var_64)) < 1e-6
     import c_oracle
     post = c_oracle.fit(x, y, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3)

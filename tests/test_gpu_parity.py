@@ -248,27 +248,29 @@ def test_gemm_sliced_int8_is_the_host_restatement_bit_for_bit():
 
 
 def test_gemm_sliced_int8_k_chunks_cannot_overflow():
-    """K beyond one 16384-chunk on the worst case the digits allow: every entry of a row equal (top digit 126 or 127), the lower
+    """K beyond one chunk on the worst case the digits allow: every entry of a row equal (top digit 126 or 127), the lower
     digits -128 or 127 by choice of the value, all products of one sign -- the int32 accumulators hold up to 2^30.9 per chunk.
-    The host restatement sums in int64: equality means no accumulator wrapped."""
+    The host restatement sums in int64: equality means no accumulator wrapped.  5 x 5 planes (up to 5 pairs on a diagonal): chunks
+    of 16384; 3 x 5 planes (round 4: at most 3 pairs on a diagonal): ONE chunk of 40960, 3 x 40960 x 2^14 = 2^30.9."""
     from oracle import c_abi
     import ctypes
-    m, n, k = 128, 256, 2 * 16384 + 640
+    m, n = 128, 256
     lib = c_abi.lib()
     vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
-    for digits in ((126, -128, -128, -128, -128), (125, 127, 127, 127, 127)):
-        # every entry = -(sum digits 256^-(i+1)) of the row scale 1 (row maximum 0.49.. = f 2^-1 with f <= 126/128)
-        frac = sum(d * 256.0 ** -(i + 1) for i, d in enumerate(digits))
-        a = np.full((m, k), -frac)
-        b = np.full((n, k), -frac)
-        b[5] *= 0.5
-        host = np.full((1, 8), np.nan)
-        assert lib.nngp_gemm_nt_i8s(vp(host), 8, None, 0, vp(a[:1].copy()), k, vp(b[:8].copy()), k, 1, 8, k, 1.0, 0.0, 5, 5, 4, None) == 0
-        c = torch.full((m, n), float("nan"), device=G.dev(), dtype=torch.float64)
-        G.gemm_nt_i8s(c, None, torch.from_numpy(a).to(G.dev()), torch.from_numpy(b).to(G.dev()), 1.0, 0.0, 5, 5, 4)
-        got = c.cpu().numpy()
-        assert np.all(got[:, np.arange(n) != 5] == host[0, 0]) and np.all(got[:, 5] == host[0, 5])
-        assert abs(host[0, 0] - (a[0] @ b[0])) < 1e-9 * abs(a[0] @ b[0])
+    for sa, k in ((5, 2 * 16384 + 640), (3, 40960)):
+        for digits in ((126, -128, -128, -128, -128), (125, 127, 127, 127, 127)):
+            # every entry = -(sum digits 256^-(i+1)) of the row scale 1 (row maximum 0.49.. = f 2^-1 with f <= 126/128)
+            frac = sum(d * 256.0 ** -(i + 1) for i, d in enumerate(digits))
+            a = np.full((m, k), -sum(d * 256.0 ** -(i + 1) for i, d in enumerate(digits[:sa])))
+            b = np.full((n, k), -frac)
+            b[5] *= 0.5
+            host = np.full((1, 8), np.nan)
+            assert lib.nngp_gemm_nt_i8s(vp(host), 8, None, 0, vp(a[:1].copy()), k, vp(b[:8].copy()), k, 1, 8, k, 1.0, 0.0, sa, 5, 4, None) == 0
+            c = torch.full((m, n), float("nan"), device=G.dev(), dtype=torch.float64)
+            G.gemm_nt_i8s(c, None, torch.from_numpy(a).to(G.dev()), torch.from_numpy(b).to(G.dev()), 1.0, 0.0, sa, 5, 4)
+            got = c.cpu().numpy()
+            assert np.all(got[:, np.arange(n) != 5] == host[0, 0]) and np.all(got[:, 5] == host[0, 5])
+            assert abs(host[0, 0] - (a[0] @ b[0])) < 1e-9 * abs(a[0] @ b[0])
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (1024, 1280, 4096), (512, 2304, 20000)])
