@@ -636,6 +636,11 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
         NNGP_HIP_CHECK(hipEventRecord(m->ev_lt, m->solve_stream));
     }
     NNGP_TRY(apply_forward_f32(m, mp, s));
+    if (NNGP_KNOB(2) == 10 && !m->gate_recorded && m->solve_pending) {  // timing experiment: the deferred alpha CG starts with the backward solve
+        if (m->ev_gate == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_gate, hipEventDisableTiming));
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_gate, s));
+        m->gate_recorded = true;
+    }
     if (lt_aside) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_lt, 0));
     if (NNGP_KNOB(7) == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
     if (use_split_solves(m, mp)) {
