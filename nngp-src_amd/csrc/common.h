@@ -105,6 +105,7 @@ struct BuildArgs {
     double diag_add_nngp32;  // added on the diagonal of the float32 outputs (regulariser), sym only
     double diag_add_ntk32;
     int lower32;        // 1: float32 outputs only get the lower triangle (factorisation input)
+    const double* comp; // set by launch_kernel_build itself: the composite ReLU map's table (kernel_build.hip), or NULL
 };
 int launch_row_sqnorm(const double* x, int64_t n, int d, double* q, hipStream_t s);
 int launch_diag_from_q(const double* q, int64_t n, const ArchDev& arch, double* dn, double* dt, hipStream_t s);

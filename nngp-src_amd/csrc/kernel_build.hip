@@ -13,6 +13,9 @@
 // perturbs posterior means by ~2.5e-4, over the 1e-4 parity gate.
 #include "common.h"
 #include "trig_tab.h"
+#include <math.h>
+#include <mutex>
+#include <vector>
 
 namespace nngp {
 
@@ -25,6 +28,8 @@ constexpr int LDM = KT + 16; // staging stride of the MFMA variant: 2*LDM = 32 (
                              // v_mfma_f64_16x16x4 fragment read touches fall on disjoint bank halves (conflict free)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr double kPi = 3.14159265358979323846;
+constexpr int kCompNI = 16, kCompDeg = 10;                       // intervals of [0, pi] and polynomial degree of the composite map
+constexpr int kCompSize = kCompNI * (kCompDeg + 1) + 1;          // + the amplitude A
 
 __global__ __launch_bounds__(256) void k_row_sqnorm(const double* __restrict__ x, int64_t n, int d,
                                                     double* __restrict__ q) {
@@ -366,13 +371,17 @@ constexpr int TLD = 34;       // row stride of the per-wave 16 x 32 output buffe
 // MKC: k-chunk; PREFETCH: the next chunk's global loads are issued into registers before the MFMAs of the current one;
 // MINWG: workgroups per CU the register allocation must allow; LDSOUT: tile + mirror leave through the LDS buffer with 16-byte
 // stores (false: the tile itself is stored straight from the accumulator layout, 8 bytes per lane).
-template <int MKC, bool PREFETCH, int MINWG, bool LDSOUT>
+// COMP (round 4): NNGP outputs only, no biases, >= 2 ReLU layers -- the whole layer recursion is then sqrt(q q') A G(pi - theta0) with ONE
+// univariate function G of the first layer's angle (comp_table below): one sqrt + one arctangent + a degree-10 polynomial per entry
+// instead of a sqrt and an arctangent per layer.  a.comp: [kCompNI][kCompDeg + 1] coefficients + A, staged in LDS.
+template <int MKC, bool PREFETCH, int MINWG, bool LDSOUT, bool COMP>
 __global__ __launch_bounds__(256, MINWG) void k_build_mfma(BuildArgs a, ArchDev arch, int64_t tiles_r, int64_t tiles_c,
                                                            int64_t sup_r, int64_t sup_c, int vec_ok, int ablate) {
     constexpr int MLD = MKC + 2;  // LDS row stride (doubles): rows 16-byte aligned, quarter-waves on distinct banks
     constexpr int NLD = MKC * 64 / 256;  // doubles per thread and operand per chunk
     __shared__ __attribute__((aligned(16))) double smem[2 * KT * MLD];  // As | Bs in the k-loop, 4 output buffers afterwards
     __shared__ __attribute__((aligned(16))) double tab[65 * 4];
+    __shared__ double ctab[COMP ? kCompSize : 1];
     static_assert(4 * 16 * TLD <= 2 * KT * MLD, "the output buffers alias the panel buffers");
     double* As = smem;             // [KT][MLD]
     double* Bs = smem + KT * MLD;  // [KT][MLD]
@@ -399,6 +408,8 @@ __global__ __launch_bounds__(256, MINWG) void k_build_mfma(BuildArgs a, ArchDev 
     const int64_t i0 = a.row_begin + bi * KT, j0 = bj * KT;
     const int64_t i_end = a.row_end, j_end = a.n2;
     for (int i = tid; i < 65 * 4; i += 256) tab[i] = kTrigTab[i >> 2][i & 3];
+    if (COMP)
+        for (int i = tid; i < kCompSize; i += 256) ctab[i] = a.comp[i];
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, lg = lane >> 4;
@@ -489,6 +500,34 @@ __global__ __launch_bounds__(256, MINWG) void k_build_mfma(BuildArgs a, ArchDev 
                 kv[j][r] = dg[r] ? q1v[r] : av[r] * inv_d;  // exact diagonal: q q' - k^2 == 0 must hold exactly
                 tv[j][r] = 0.0;
             }
+            if (COMP) {
+                const double amp = ctab[kCompSize - 1];  // A = prod w2 / 2^n_relu
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double k = kv[j][r];
+                    if (dg[r]) {  // theta = 0 exactly: the closed-form diagonal, in the recursion's own order of operations
+                        for (int l = 0; l < arch.n_dense; ++l) {
+                            k = arch.w2[l] * k;
+                            if (l < arch.n_dense - 1) k *= 0.5;
+                        }
+                    } else {
+                        const double qq = q1v[r] * q2v;
+                        const double rr = fma(q1v[r], q2v, -k * k);
+                        const double sn = rr > 0.0 ? fast_sqrt_pos(rr > 0.0 ? rr : 1.0) : 0.0;
+                        const double pmt = pi_minus_atan2(sn, k, tab);  // pi - theta0 in [0, pi]
+                        int iv = (int)(pmt * (kCompNI / kPi));
+                        iv = iv < 0 ? 0 : (iv > kCompNI - 1 ? kCompNI - 1 : iv);
+                        const double u = fma(pmt, 2.0 * kCompNI / kPi, -(double)(2 * iv + 1));  // (pmt - mid) / half-width
+                        const double* cf = ctab + iv * (kCompDeg + 1);
+                        double p = cf[kCompDeg];
+#pragma unroll
+                        for (int e = kCompDeg - 1; e >= 0; --e) p = fma(p, u, cf[e]);
+                        const double rho = qq > 0.0 ? fast_sqrt_pos(qq > 0.0 ? qq : 1.0) : 0.0;
+                        k = rho * (amp * p);
+                    }
+                    kv[j][r] = k;
+                }
+            } else
             for (int l = 0; l < arch.n_dense; ++l) {
                 const double w2 = arch.w2[l], b2 = arch.b2[l];
                 const bool relu = l < arch.n_dense - 1 && !(ablate & 4);
@@ -633,7 +672,102 @@ static int device_cus() {
     return n;
 }
 
-int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) {
+// ---- the composite ReLU map (round 4) --------------------------------------------------------------------------------------
+// Without biases the layer recursion is homogeneous: a Dense layer scales k, q, q' alike and a ReLU layer maps the cosine
+// c = k / sqrt(q q') to J(theta) / pi, J(theta) = sin theta + (pi - theta) cos theta, theta = acos c, while q halves.  So after all
+// layers   K = sqrt(q q') A F(theta0),   A = prod w2 / 2^n_relu,   F = (J / pi) o acos o ... o (J / pi)  (n_relu maps)
+// -- ONE univariate function of the FIRST layer's angle, analytic on [0, pi] (at theta0 = 0 the inner acos meets
+// 1 - theta0^2 / 2 + theta0^3 / (3 pi) ...: theta1 = theta0 sqrt(1 - 2 theta0 / (3 pi) ...)).  The kernel evaluates
+// G(t) = F(pi - t) on kCompNI intervals of t = pi - theta0 (the quantity pi_minus_atan2 returns) by a degree-kCompDeg polynomial
+// in the interval's own variable u in [-1, 1]: Chebyshev interpolation of the recursion evaluated in long double here, turned into
+// monomial coefficients, CHECKED in double Horner arithmetic against the long-double recursion (<= 4e-16 absolute where G >= 1 / pi,
+// else the table is refused and the kernel keeps the per-layer recursion).  Measured accuracy for 2..4 ReLU layers: 1.1e-16.
+struct CompEntry {
+    int n_dense;
+    double w2[NNGP_MAX_DENSE];
+    const double* dev;  // NULL: refused
+};
+static std::mutex g_comp_mu;
+static std::vector<CompEntry> g_comp;
+
+static long double comp_exact(long double t, int n_relu) {
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double th = pi - t, c = 0.0L;
+    for (int l = 0; l < n_relu; ++l) {
+        if (l > 0) th = acosl(c > 1.0L ? 1.0L : (c < -1.0L ? -1.0L : c));
+        c = (sinl(th) + (pi - th) * cosl(th)) / pi;
+    }
+    return c;
+}
+
+static bool comp_build_host(const ArchDev& arch, double* out) {
+    const int n_relu = arch.n_dense - 1, D = kCompDeg;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    // Chebyshev polynomials T_0 .. T_D as monomial coefficients
+    long double T[kCompDeg + 1][kCompDeg + 1] = {};
+    T[0][0] = 1.0L;
+    T[1][1] = 1.0L;
+    for (int n = 2; n <= D; ++n)
+        for (int k = 0; k <= n; ++k) T[n][k] = (k > 0 ? 2.0L * T[n - 1][k - 1] : 0.0L) - T[n - 2][k];
+    double worst = 0.0;
+    for (int i = 0; i < kCompNI; ++i) {
+        const long double a = pi / (2.0L * kCompNI), m = (2 * i + 1) * a;
+        long double f[kCompDeg + 1], cheb[kCompDeg + 1], mono[kCompDeg + 1] = {};
+        for (int k = 0; k <= D; ++k) f[k] = comp_exact(m + a * cosl(pi * (k + 0.5L) / (D + 1)), n_relu);
+        for (int j = 0; j <= D; ++j) {
+            long double sum = 0.0L;
+            for (int k = 0; k <= D; ++k) sum += f[k] * cosl(j * pi * (k + 0.5L) / (D + 1));
+            cheb[j] = sum * 2.0L / (D + 1);
+        }
+        cheb[0] *= 0.5L;
+        for (int j = 0; j <= D; ++j)
+            for (int k = 0; k <= j; ++k) mono[k] += cheb[j] * T[j][k];
+        double* cf = out + i * (D + 1);
+        for (int k = 0; k <= D; ++k) cf[k] = (double)mono[k];
+        for (int e = 0; e <= 64; ++e) {  // the check, in the kernel's own arithmetic
+            const double u = -1.0 + e / 32.0;
+            double p = cf[D];
+            for (int k = D - 1; k >= 0; --k) p = fma(p, u, cf[k]);
+            const double err = fabs((double)((long double)p - comp_exact(m + a * (long double)u, n_relu)));
+            worst = err > worst ? err : worst;
+        }
+    }
+    double amp = 1.0;
+    for (int l = 0; l < arch.n_dense; ++l) amp *= arch.w2[l];
+    out[kCompSize - 1] = ldexp(amp, -n_relu);
+    return worst <= 4e-16;
+}
+
+// the table of this architecture on the device (built once per process and architecture), or NULL when the composite form does
+// not apply: biases, fewer than two ReLU layers, a table that failed its check
+static const double* comp_table(const ArchDev& arch) {
+    if (arch.n_dense < 3) return nullptr;
+    for (int l = 0; l < arch.n_dense; ++l)
+        if (arch.b2[l] != 0.0 || !(arch.w2[l] > 0.0)) return nullptr;
+    std::lock_guard<std::mutex> lock(g_comp_mu);
+    for (const CompEntry& e : g_comp)
+        if (e.n_dense == arch.n_dense && memcmp(e.w2, arch.w2, sizeof(double) * arch.n_dense) == 0) return e.dev;
+    CompEntry e{};
+    e.n_dense = arch.n_dense;
+    memcpy(e.w2, arch.w2, sizeof(double) * arch.n_dense);
+    std::vector<double> host(kCompSize);
+    double* dev = nullptr;
+    if (comp_build_host(arch, host.data()) && hipMalloc(reinterpret_cast<void**>(&dev), sizeof(double) * kCompSize) == hipSuccess) {
+        if (hipMemcpy(dev, host.data(), sizeof(double) * kCompSize, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(dev);
+            dev = nullptr;
+        }
+    }
+    (void)hipGetLastError();
+    e.dev = dev;
+    g_comp.push_back(e);
+    return dev;
+}
+
+int launch_kernel_build(const BuildArgs& a_in, const ArchDev& arch, hipStream_t s) {
+    BuildArgs a = a_in;
+    // NNGP outputs only, no biases, >= 2 ReLU layers: the composite map (debug key 5 = 63: the per-layer recursion)
+    a.comp = (a.ntk64 == nullptr && a.ntk32 == nullptr && NNGP_KNOB(5) != 63) ? comp_table(arch) : nullptr;
     const int64_t rows = a.row_end - a.row_begin;
     if (rows <= 0 || a.n2 <= 0) return 0;
     NNGP_REQUIRE(a.d > 0, "kernel_build: d must be positive");
@@ -675,7 +809,7 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
         const int ablate = NNGP_KNOB(3) >= 32 && NNGP_KNOB(3) < 40 ? NNGP_KNOB(3) - 32 : 0;  // timing ablations (wrong results)
         const int variant = NNGP_KNOB(5) >= 20 && NNGP_KNOB(5) < 30 ? NNGP_KNOB(5) - 20 : 0;  // A/B timing of the kernel forms
 #define NNGP_K1_LAUNCH(KC_, PF_, WG_, LO_) \
-        hipLaunchKernelGGL((k_build_mfma<KC_, PF_, WG_, LO_>), dim3((unsigned)grid), dim3(256), 0, s, a, arch, tiles_r, tiles_c, sup_r, sup_c, vec_ok, ablate)
+        hipLaunchKernelGGL((k_build_mfma<KC_, PF_, WG_, LO_, false>), dim3((unsigned)grid), dim3(256), 0, s, a, arch, tiles_r, tiles_c, sup_r, sup_c, vec_ok, ablate)
         switch (variant) {
 #ifdef NNGP_TIMING_KNOBS  // measured (scripts/k1_variants.py, ms at N = 32768, d = 128, n_relu = 3; all stores / no stores):
             case 1: NNGP_K1_LAUNCH(16, false, 4, true); break;   // 7.66 / 5.82  (29 registers spilled)
@@ -685,7 +819,13 @@ int launch_kernel_build(const BuildArgs& a, const ArchDev& arch, hipStream_t s) 
             case 5: NNGP_K1_LAUNCH(16, true, 4, false); break;   // 7.00 / 5.81  (24 spilled)
             case 7: NNGP_K1_LAUNCH(32, false, 4, false); break;  // 7.23 / 5.81  (24 spilled)
 #endif
-            default: NNGP_K1_LAUNCH(16, true, 3, false); break;  // 6.7 ms at N = 32768, d = 128, n_relu = 3 (round 1: 10.1)
+            default:
+                if (a.comp != nullptr && ablate == 0)
+                    hipLaunchKernelGGL((k_build_mfma<16, true, 3, false, true>), dim3((unsigned)grid), dim3(256), 0, s, a, arch, tiles_r, tiles_c,
+                                       sup_r, sup_c, vec_ok, ablate);
+                else
+                    NNGP_K1_LAUNCH(16, true, 3, false);  // 6.7 ms at N = 32768, d = 128, n_relu = 3 (round 1: 10.1)
+                break;
         }
 #undef NNGP_K1_LAUNCH
     }

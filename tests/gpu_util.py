@@ -11,8 +11,8 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def kernel_build(x1, x2, w_std, b_std, get=("nngp", "ntk"), rows=None, dtype=torch.float64, ld=None):
-    lib = _lib.load()
+def kernel_build(x1, x2, w_std, b_std, get=("nngp", "ntk"), rows=None, dtype=torch.float64, ld=None, knobs=False):
+    lib = _lib.load(knobs=knobs)
     x1d = _lib.to_device_f64(x1, dev())
     x2d = None if x2 is None else _lib.to_device_f64(x2, dev())
     n1, d = x1d.shape

@@ -80,6 +80,59 @@ def test_kernel_build_edge_values():
     np.testing.assert_allclose(f32["nngp"], out["nngp"], rtol=2e-7, atol=1e-30)
 
 
+@pytest.mark.parametrize("n_relu,w", [(2, 1.0), (3, 1.3), (4, 0.8)])
+def test_kernel_build_composite_relu_map(n_relu, w):
+    """Round 4 (reference op: kernel_fn of stax.serial(Dense, Relu, ..., Dense), train.py:161-164, whose Dense layers have no bias):
+    without biases the layer recursion is sqrt(q q') A F(theta0) with ONE univariate function of the first layer's angle, which
+    the kernel evaluates by a checked piecewise polynomial (kernel_build.hip: comp_table) instead of a sqrt and an arctangent per
+    layer.  Entries against a 40-digit evaluation of the recursion itself -- random pairs, duplicate, nearly parallel, antiparallel,
+    orthogonal and zero rows -- and against the per-layer path (timing-knob key 5 = 63); the diagonal is the closed form, bit for bit."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    rng = np.random.default_rng(17 + n_relu)
+    x = rng.uniform(-1.0, 3.0, size=(260, 16))
+    x[1] = x[0]
+    x[2] = x[0] * (1.0 + 1e-9) + 1e-7 * rng.standard_normal(16)
+    x[3] = -x[0]
+    x[4] = 0.0
+    x[5] = 0.0; x[5, 0] = 2.0
+    x[6] = 0.0; x[6, 1] = 5.0
+    a = o.make_arch(n_relu, w, 0.0)
+    got = G.kernel_build(x, None, a.w_std, a.b_std, get=("nngp",), knobs=True)["nngp"]
+    from nngp_src_amd import _lib as L
+    L.load(knobs=True).nngp_debug_set(5, 63)
+    try:
+        layered = G.kernel_build(x, None, a.w_std, a.b_std, get=("nngp",), knobs=True)["nngp"]
+    finally:
+        L.load(knobs=True).nngp_debug_set(5, 0)
+    assert np.array_equal(got, got.T) and np.array_equal(np.diag(got), np.diag(layered))
+    scale = np.sqrt(np.outer(np.diag(got), np.diag(got)))
+    assert np.max(np.abs(got - layered) / np.maximum(scale, 1e-300)) < 2e-13   # the per-layer path loses digits on nearly parallel rows
+    assert np.all(got[4] == 0.0)
+
+    def exact(i, j):
+        q1, q2, k = (mp.fsum(mp.mpf(float(v)) ** 2 for v in x[i]) / 16, mp.fsum(mp.mpf(float(v)) ** 2 for v in x[j]) / 16,
+                     mp.fsum(mp.mpf(float(u)) * mp.mpf(float(v)) for u, v in zip(x[i], x[j])) / 16)
+        w2 = mp.mpf(float(a.w_std[0])) ** 2
+        for l in range(n_relu + 1):
+            q1, q2, k = w2 * q1, w2 * q2, w2 * k
+            if l < n_relu:
+                c = k / mp.sqrt(q1 * q2)
+                th = mp.acos(max(mp.mpf(-1), min(mp.mpf(1), c)))
+                k = mp.sqrt(q1 * q2) * (mp.sin(th) + (mp.pi - th) * mp.cos(th)) / (2 * mp.pi)
+                q1, q2 = q1 / 2, q2 / 2
+        return k
+    pairs = [(1, 0), (2, 0), (3, 0), (6, 5), (5, 0), (7, 0)] + [tuple(rng.integers(7, 260, 2)) for _ in range(60)]
+    worst = 0.0
+    for i, j in pairs:
+        if i == j:
+            continue
+        ref = exact(int(i), int(j))
+        worst = max(worst, float(abs(mp.mpf(float(got[i, j])) - ref) / mp.mpf(float(scale[i, j]))))
+    # the Gram entry itself carries ~1e-16 d of rounding; a duplicate / nearly parallel pair turns that into sqrt(rounding) of angle
+    assert worst < 3e-14, worst
+
+
 def test_kernel_build_empty_inputs():
     a = o.make_arch(1)
     out = G.kernel_build(np.zeros((0, 5)), None, a.w_std, a.b_std)
