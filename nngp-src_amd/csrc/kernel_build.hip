@@ -683,6 +683,7 @@ static int device_cus() {
 // monomial coefficients, CHECKED in double Horner arithmetic against the long-double recursion (<= 4e-16 absolute where G >= 1 / pi,
 // else the table is refused and the kernel keeps the per-layer recursion).  Measured accuracy for 2..4 ReLU layers: 1.1e-16.
 struct CompEntry {
+    int device;
     int n_dense;
     double w2[NNGP_MAX_DENSE];
     const double* dev;  // NULL: refused
@@ -744,10 +745,13 @@ static const double* comp_table(const ArchDev& arch) {
     if (arch.n_dense < 3) return nullptr;
     for (int l = 0; l < arch.n_dense; ++l)
         if (arch.b2[l] != 0.0 || !(arch.w2[l] > 0.0)) return nullptr;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_comp_mu);
     for (const CompEntry& e : g_comp)
-        if (e.n_dense == arch.n_dense && memcmp(e.w2, arch.w2, sizeof(double) * arch.n_dense) == 0) return e.dev;
+        if (e.device == device && e.n_dense == arch.n_dense && memcmp(e.w2, arch.w2, sizeof(double) * arch.n_dense) == 0) return e.dev;
     CompEntry e{};
+    e.device = device;
     e.n_dense = arch.n_dense;
     memcpy(e.w2, arch.w2, sizeof(double) * arch.n_dense);
     std::vector<double> host(kCompSize);
