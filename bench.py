@@ -411,6 +411,9 @@ def main():
             if rtimer["on"]:  # ... and around every int8 plane-product launch of this step's predict
                 nl, tms, tfl, tops = model.residual_timer_read()
                 rtimer["launches"] += nl; rtimer["ms"] += tms; rtimer["flops"] += tfl; rtimer["ops"] += tops
+            if stimer["on"]:  # ... and around every blocked triangular solve of this step's predict
+                nl, tms, tfl = model.trsm_timer_read()
+                stimer["solves"] += nl; stimer["ms"] += tms; stimer["flops"] += tfl
             for k, (a, b) in {"set_train": (e0, e1), "kernel_build": (e1, e2), "allgather": (e2, e3),
                               "cholesky": (e3, e4), "alpha_solve": (e4, e5), "posterior": (e5, e6)}.items():
                 stages.setdefault(k, []).append(a.elapsed_time(b))
@@ -443,11 +446,20 @@ def main():
         rtimer["on"] = True
     except _lib.NngpError:
         pass
+    # ... and of the posterior's blocked triangular solves for `roofline_solves`
+    stimer = {"on": False, "solves": 0, "ms": 0.0, "flops": 0.0}
+    try:
+        model.trsm_timer(True)
+        stimer["on"] = True
+    except _lib.NngpError:
+        pass
     for _ in range(args.warmup):
         step()
     barrier()
     if rtimer["on"]:
         model.residual_timer_read()  # drop the warm-up launches
+    if stimer["on"]:
+        model.trsm_timer_read()
     stages = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -622,6 +634,20 @@ def main():
                 "note": "the float64 matrix pipe peaks at 78.6 TF/s (the kernel this replaced ran the same product at 68); the chip holds "
                         "~1.6 GHz under this load (profiles/r3_i8s_pmc_summary.txt: MFMA pipe 73 % busy)",
                 "timer": "HIP events on the caller's stream around each launch (library: nngp_model_residual_timer), timed steps only",
+            }
+        if stimer["on"] and stimer["solves"] > 0 and stimer["ms"] > 0.0:
+            # the kernel chain furthest below its pipe: the posterior's blocked triangular solves (split-float16 updates in steps of
+            # 1024 columns + float32 diagonal products), HIP events on the caller's stream around each solve
+            s_tf = stimer["flops"] / (stimer["ms"] * 1e-3) / 1e12
+            result["roofline_solves"] = {
+                "bound": "mfma", "achieved": round(s_tf, 1), "peak": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
+                "frac": round(s_tf / (PEAK_F16_MFMA_TFLOPS / 3.0), 4),
+                "kernel": "blocked triangular solves of the posterior (k_gemm_nt_h3v2<LOWER=false> updates + k_gemm_nt_f32 diagonal products + "
+                          "k_split_rows_rowscale), N^2 M algorithmic flops per solve",
+                "solves_per_step": round(stimer["solves"] / args.steps, 2), "ms_per_step": round(stimer["ms"] / args.steps, 3),
+                "note": "a latency chain of N / 1024 steps with M / 256 tile rows per step (DESIGN.md section 8); the first solve of a fit "
+                        "shares the chip with the cut of K's digit planes, the last one with the alpha CG",
+                "timer": "HIP events on the caller's stream around each solve (library: nngp_model_trsm_timer), timed steps only",
             }
         if shard_report is not None:
             result["shard"] = shard_report

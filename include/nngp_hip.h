@@ -185,6 +185,13 @@ int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total);
  * (x the number of plane pairs), then starts over.  Any out pointer may be NULL. */
 int nngp_model_residual_timer(nngp_model* m, int32_t enable);
 int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total, double* int8_ops_total);
+/* Live timing of the posterior's blocked triangular solves (solve.hip: trsm_rlt_blocks_h3 / trsm_rut_blocks_h3 and their float32
+ * forms; reference op: the K_dd^-1 products inside predict_fn(..., compute_cov=True), train.py:157-158): with the timer on, every
+ * forward or backward solve of a block of right-hand sides is bracketed by a pair of HIP events on the caller's stream.  _read waits
+ * for them and returns what ran since the last read -- the solves, their summed duration and their algorithmic flops (N^2 M each: a
+ * triangular matrix against M right-hand sides) -- then starts over.  At most 32 solves are kept between reads. */
+int nngp_model_trsm_timer(nngp_model* m, int32_t enable);
+int nngp_model_trsm_timer_read(nngp_model* m, int64_t* solves, double* ms_total, double* flops_total);
 /* Guard of that path.  The first predict of a fit that forms a level-1 variance with the int8 residual also estimates what the
  * digit pairs it dropped may have cost the variances (|z|_2 x the dropped pairs' random-sign sum, relative to each variance; maximum
  * over the rows) and reads it back once; above 1e-5 the predict is redone with the float64 product and the fit stays on the float64

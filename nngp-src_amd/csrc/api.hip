@@ -162,6 +162,14 @@ struct nngp_model {
     // ~17 small launches, 0.5 ms at N = 32768, that leaves the chip idle when it runs in line); every other consumer builds them in
     // order.  tri_join() is the one gate: every reader of `tri` passes it on the stream it reads from.
     bool tri_stale = false, tri_pending = false;
+    // live timing of the posterior's blocked triangular solves (nngp_model_trsm_timer): one event pair per forward / backward solve
+    struct TrsmTimer {
+        static constexpr int kMax = 32;
+        bool timed = false;
+        int count = 0;
+        hipEvent_t t0[kMax] = {}, t1[kMax] = {};
+        double flops[kMax] = {};
+    } trsm_t;
     hipEvent_t ev_tri = nullptr, ev_tri_fork = nullptr;
     hipEvent_t ev_ready = nullptr, ev_solved = nullptr;
     hipEvent_t ev_lt = nullptr;  // orders the split copy of L^T written on solve_stream (apply_inverse_f32)
@@ -191,6 +199,7 @@ struct nngp_model {
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_lt) (void)hipEventDestroy(ev_lt);
         if (ev_tri) (void)hipEventDestroy(ev_tri);
+        for (int t = 0; t < TrsmTimer::kMax; ++t) { if (trsm_t.t0[t]) (void)hipEventDestroy(trsm_t.t0[t]); if (trsm_t.t1[t]) (void)hipEventDestroy(trsm_t.t1[t]); }
         if (ev_tri_fork) (void)hipEventDestroy(ev_tri_fork);
         if (ev_solved) (void)hipEventDestroy(ev_solved);
         if (ev_predict) (void)hipEventDestroy(ev_predict);
@@ -610,9 +619,38 @@ bool use_split_solves(const nngp_model* m, int64_t mp) {
            m->tri.bs / m->split.k_cap <= m->split.b_panels && m->tri.bs <= 2048 && NNGP_KNOB(7) == 0 && mp >= 256 && mp * m->np >= 7000000;
 }
 
+// event pair around one blocked solve of mp right-hand sides (np^2 mp flops: a triangular matrix, multiply-add = 2)
+static int trsm_timer_begin(nngp_model* m, int64_t mp, hipStream_t s, int* slot) {
+    auto& t = m->trsm_t;
+    *slot = -1;
+    if (!t.timed || t.count >= nngp_model::TrsmTimer::kMax) return 0;
+    const int i = t.count;
+    if (t.t0[i] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&t.t0[i]));
+    if (t.t1[i] == nullptr) NNGP_HIP_CHECK(hipEventCreate(&t.t1[i]));
+    NNGP_HIP_CHECK(hipEventRecord(t.t0[i], s));
+    t.flops[i] = (double)m->np * (double)m->np * (double)mp;
+    *slot = i;
+    return 0;
+}
+static int trsm_timer_end(nngp_model* m, int slot, hipStream_t s) {
+    if (slot < 0) return 0;
+    NNGP_HIP_CHECK(hipEventRecord(m->trsm_t.t1[slot], s));
+    m->trsm_t.count = slot + 1;
+    return 0;
+}
+
+static int apply_forward_untimed(nngp_model* m, int64_t mp, hipStream_t s);
+
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
 int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     NNGP_TRY(tri_join(m, s));
+    int slot = -1;
+    NNGP_TRY(trsm_timer_begin(m, mp, s, &slot));
+    NNGP_TRY(apply_forward_untimed(m, mp, s));
+    return trsm_timer_end(m, slot, s);
+}
+
+static int apply_forward_untimed(nngp_model* m, int64_t mp, hipStream_t s) {
     // While the deferred alpha CG runs on its own stream (from the int8 residual's gate on), the solves' persistent update grids
     // leave it some compute units (debug key 13 = n: n units; default 0 = none -- see DESIGN_NOTES R4)
     m->split.solve_reserve = (m->gate_recorded && NNGP_KNOB(13) > 0) ? NNGP_KNOB(13) : 0;
@@ -643,11 +681,14 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     }
     if (lt_aside) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_lt, 0));
     if (NNGP_KNOB(7) == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
-    if (use_split_solves(m, mp)) {
-        NNGP_TRY(ensure_lt_split(m, s));
-        return trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt_ready ? m->lt32 : nullptr, m->np, m->tri, m->np, m->trsm_tmp, m->split, s);
-    }
-    return trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s);
+    if (use_split_solves(m, mp)) NNGP_TRY(ensure_lt_split(m, s));
+    int slot = -1;
+    NNGP_TRY(trsm_timer_begin(m, mp, s, &slot));
+    if (use_split_solves(m, mp))
+        NNGP_TRY(trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt_ready ? m->lt32 : nullptr, m->np, m->tri, m->np, m->trsm_tmp, m->split, s));
+    else
+        NNGP_TRY(trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s));
+    return trsm_timer_end(m, slot, s);
 }
 
 // NTK covariance: the error of Z enters in first order (no cancellation as in the NNGP form), so what the sweeps leave is
@@ -1353,6 +1394,31 @@ int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_
     if (flops_total) *flops_total = fl;
     if (int8_ops_total) *int8_ops_total = ops;
     w.t_count = 0;
+    return 0;
+}
+
+int nngp_model_trsm_timer(nngp_model* m, int32_t enable) {
+    NNGP_REQUIRE(m != nullptr, "trsm_timer: NULL model");
+    m->trsm_t.timed = enable != 0;
+    m->trsm_t.count = 0;
+    return 0;
+}
+
+int nngp_model_trsm_timer_read(nngp_model* m, int64_t* solves, double* ms_total, double* flops_total) {
+    NNGP_REQUIRE(m != nullptr, "trsm_timer_read: NULL model");
+    auto& w = m->trsm_t;
+    double ms = 0.0, fl = 0.0;
+    for (int t = 0; t < w.count; ++t) {
+        NNGP_HIP_CHECK(hipEventSynchronize(w.t1[t]));
+        float e = 0.0f;
+        NNGP_HIP_CHECK(hipEventElapsedTime(&e, w.t0[t], w.t1[t]));
+        ms += e;
+        fl += w.flops[t];
+    }
+    if (solves) *solves = w.count;
+    if (ms_total) *ms_total = ms;
+    if (flops_total) *flops_total = fl;
+    w.count = 0;
     return 0;
 }
 

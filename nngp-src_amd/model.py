@@ -257,6 +257,17 @@ class GPModel:
         self._check(self.lib.nngp_model_residual_timer_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ops)))
         return int(n.value), float(ms.value), float(fl.value), float(ops.value)
 
+    def trsm_timer(self, enable=True):
+        """Live HIP-event timing of the posterior's blocked triangular solves; see trsm_timer_read."""
+        self._check(self.lib.nngp_model_trsm_timer(self.handle, 1 if enable else 0))
+
+    def trsm_timer_read(self):
+        """(solves, total ms, algorithmic flops N^2 M each) since the last read (waits for them)."""
+        n = ctypes.c_int64(0)
+        ms, fl = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self.lib.nngp_model_trsm_timer_read(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        return int(n.value), float(ms.value), float(fl.value)
+
     def residual_floor(self):
         """(estimate, distrusted): what the int8 residual's dropped digit pairs may have cost this fit's level-1 variances, relative
         to them (-1.0 until a predict measured it), and whether the fit was taken off the int8 path for it."""

@@ -548,7 +548,11 @@ def test_int8_residual_path_against_the_float64_residual():
     xt, _ = synth.synthetic_queries(300, 24, seed=42)
     model = GPModel(2600, 24, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, knobs=True).fit(x, y)
     model.residual_timer(True)
+    model.trsm_timer(True)
     mean_i8, var_i8 = model.predict(xt, cov="diag")
+    solves, sms, sflops = model.trsm_timer_read()   # level 1: forward + backward solve of k, forward solve of the residual
+    assert solves == 3 and sflops == 3.0 * 2688 * 2688 * 384 and sms > 0.0 and model.trsm_timer_read()[0] == 0
+    model.trsm_timer(False)
     launches, ms, flops, ops = model.residual_timer_read()
     assert launches == 1 and ops == 12 * flops and flops == 2.0 * 384 * 2688 * 2688 and ms > 0.0  # 3 x 5 planes, i + j <= 4: 12 pairs
     ratio, distrusted = model.residual_floor()   # the guard's estimate of what the dropped digit pairs cost these variances
