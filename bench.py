@@ -5,7 +5,7 @@ One "step" = one pass of the whole hot path over one synthetic batch of encoded 
 resident in HBM: row norms + regulariser, N x N kernel build, float32 MFMA Cholesky, CG solve for alpha
 on the float64 kernel, and the posterior (cross kernel, mean, diag variance) for M test queries.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1] [--mode shard|replicate]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1] [--mode shard|shard32|replicate|grid2d]
 
 N = 1: configs[2] (cfg3, N = 32768, the north-star size).  N > 1 (launched by torch.distributed.run, one rank per GPU):
 configs[3] (cfg4, N = 65536) in the layout BASELINE.json's north star names -- rank g builds the row block

@@ -16,10 +16,10 @@ import json
 ref = None
 for g in (1, 2, 4):
     d = json.loads(open("gpurun_out/rehearsal_g%d.json" % g).read().strip().splitlines()[-1])
-    print(g, d["fit_info"], {k: round(v, 2) for k, v in d["stages_ms"].items()})
+    print(g, d["fit_info"], {k: round(v, 2) for k, v in d.get("stages_ms", {}).items()})
     if ref is None:
         ref = d["fit_info"]["alpha_l2"]
     assert abs(d["fit_info"]["alpha_l2"] - ref) <= 1e-9 * abs(ref), "alpha differs between rank counts"
-    assert d["fit_info"]["clamped_pivots"] == 0 and d["fit_info"]["rel_residual"] < 1e-9
+    assert d["fit_info"].get("clamped_pivots", 0) == 0 and d["fit_info"]["rel_residual"] < 1e-9
 print("multi-rank rehearsal OK")
 PY
