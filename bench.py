@@ -46,8 +46,8 @@ def _i8_bytes_per_launch(n_pad, m_pad, pairs):
     """Algorithmic bytes of one k_gemm_nt_i8s launch: digit planes of both operands read once + int32 plane products written once."""
     def one(nz, nk, ndiag, chunk):
         return float(nk) * n_pad * n_pad + float(nz) * m_pad * n_pad + 4.0 * ndiag * m_pad * n_pad * max(1, -(-n_pad // chunk))
-    coarse, fine = one(3, 5, 5, 40960), one(7, 7, 7, 16384)
-    f = min(1.0, max(0.0, (pairs - 12.0) / 16.0))
+    coarse, fine = one(3, 5, 5, 40960), one(5, 7, 7, 16384)
+    f = min(1.0, max(0.0, (pairs - 12.0) / 13.0))
     return (1.0 - f) * coarse + f * fine
 
 
@@ -625,7 +625,7 @@ def main():
                 "plane_pairs": round(rtimer["ops"] / rtimer["flops"], 2),
                 # algorithmic bytes per launch: the digit planes of both operands read once + the int32 plane products written once
                 # (a first residual: 5 planes of K, 3 of the rounded z, 5 diagonals in chunks of <= 40960 k -- 12 pairs; a FINE product:
-                # 7 + 7 planes, 7 diagonals in chunks of <= 16384 -- 28 pairs; a step's mix follows from its mean pair count)
+                # 7 planes of K, 5 of the rounded z, 7 diagonals in chunks of <= 16384 -- 25 pairs; a step's mix follows from its mean pair count)
                 "algorithmic_bytes_per_launch": round(_i8_bytes_per_launch(n_pad, m_pad, rtimer["ops"] / rtimer["flops"])
                                                       * (rtimer["flops"] / rtimer["launches"]) / (2.0 * m_pad * n_pad * n_pad), 1),
                 "traffic": r_traffic, "traffic_source": (traffic_src + ", k_gemm_nt_i8s, per launch") if r_traffic else traffic_note,

@@ -382,12 +382,14 @@ bool use_i8s(const nngp_model* m, int64_t mp) {
 // Two grades of the product.  COARSE: 3 x 5 planes (z ROUNDED to its three and written back, round 4; 5 x 5 before), pairs with
 // ia + ib <= 4 (12 exact plane products, 15 before; error ~2^-32 sqrt(N) of the row maxima, all of it from the kernel's side now)
 // -- for a FIRST residual.  FINE: 7 x 7 planes, ia + ib <= 6 (28 products; ~2^-48 sqrt(N): what the float64 matrix pipe
-// delivers) -- for the later residuals and the NTK's W = Z K_dd, where the coarse floor would show (see residual_rows); 28 products
+// delivers; since late round 4 z is ROUNDED to five planes there as well and written back: 5 x 7 planes, 25 products, the iterate
+// moves by 9e-13 of its row maximum) -- for the later residuals and the NTK's W = Z K_dd, where the coarse floor would show (see residual_rows); 28 products
 // still cost 3/4 of the float64 product at N = 32768.  A model that will ask for FINE products (NTK fits, covariance levels >= 2)
 // has its kernel matrix cut into 7 planes once; coarse products then read the first five of them.
 enum { I8_COARSE = 0, I8_FINE = 1 };
 constexpr int kI8FinePlanes = 7, kI8FineCut = 6;
 constexpr int kI8CoarseZPlanes = 3;  // a first residual's z is rounded to three digits and written back (i8s_product_rows)
+constexpr int kI8FineZPlanes = 5;    // a later residual's z (an iterate good to ~1e-8) and the NTK's final Z: rounded to 40 bits below the row maximum (9e-13 of it)
 
 // FINE pays later than COARSE (28 against 15 products): from N = 4096 and four 128-row tiles of right-hand sides on.  Debug key 5 = 57: off.
 bool use_i8s_fine(const nngp_model* m, int64_t mp) { return use_i8s(m, mp) && m->np >= 4096 && mp >= 512 && NNGP_KNOB(5) != 57; }
@@ -499,9 +501,11 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
     // COARSE: z comes straight from the float32 solves and every identity downstream holds for WHATEVER z they returned -- so z is
     // rounded to 24-bit fixed point below its row maximum (three planes; the solves' own error is ~1e-4 of it) and written back:
     // the planes ARE z, planes 3 and 4 do not exist, 12 plane products instead of 15 and no truncation on the z side
-    const bool round_z = grade == I8_COARSE && w.ns_z < w.ns_k;
+    // FINE (round 4, late): the same for the later residuals and the NTK's W = Z K_dd with five planes -- 25 products instead of 28 (timing-knob key 5 = 64: seven)
+    const int fine_z = NNGP_KNOB(5) == 64 ? kI8FinePlanes : kI8FineZPlanes;
+    const bool round_z = grade == I8_COARSE ? w.ns_z < w.ns_k : fine_z < kI8FinePlanes;
     const bool fuse_rows = grade == I8_COARSE && m->i8_fuse_request && cin != nullptr && w.rowpart_rows >= mp && NNGP_KNOB(5) != 59;
-    const int ns_z = grade == I8_FINE ? kI8FinePlanes : w.ns_z, ns_k = grade == I8_FINE ? kI8FinePlanes : w.ns_k;
+    const int ns_z = grade == I8_FINE ? fine_z : w.ns_z, ns_k = grade == I8_FINE ? kI8FinePlanes : w.ns_k;
     const int cut = grade == I8_FINE ? kI8FineCut : w.cut;
     NNGP_REQUIRE(pk.alloc_planes >= ns_k && w.z_planes >= ns_z, "i8s_product_rows: workspace for %d planes missing", ns_k);
     if (!pk.ready || pk.ns_done < ns_k) {
