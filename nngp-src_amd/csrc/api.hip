@@ -984,7 +984,18 @@ int nngp_model_build_rows(nngp_model* m, int64_t row_begin, int64_t row_end, voi
         a.lower32 = 1;
         m->a32_built = true;
     }
+    // An NTK model whose covariance has been asked for before keeps the NNGP kernel of its training rows beside Theta (kaux64, the
+    // K_dd of cov = K_tt + Z K_dd Z^T - ...): the layer recursion carries both kernels anyway, so the same launch writes it -- one
+    // kernel build per fit instead of two (the second one used to run inside the first covariance predict).  Same leading dimension only.
+    m->aux_ready = false;
+    const bool aux_too = a.sym && m->get == NNGP_GET_NTK && m->kaux64 != nullptr && m->ld == m->np && NNGP_KNOB(5) != 65;
+    if (aux_too) a.nngp64 = m->kaux64;
     NNGP_TRY(launch_kernel_build(a, m->arch, s));
+    if (aux_too) {
+        NNGP_TRY(launch_zero_pad_f64(m->kaux64, m->np, m->n, m->np, s));
+        m->aux_ready = true;
+        m->i8.aux.ready = false;
+    }
     NNGP_TRY(launch_zero_pad_f64(m->k64, m->ld, m->n, m->np, s));  // float64 GEMMs read the padded matrix
     m->built = true;  // the caller vouches for the remaining rows (all-gather) before factor
     m->factored = m->solved = false;
@@ -1094,8 +1105,7 @@ int nngp_model_factor_end(nngp_model* m, void* stream) {
     m->factored = true;
     m->solved = false;
     m->lt_ready = false;
-    m->aux_ready = false;
-    return 0;
+    return 0;  // (aux_ready follows the kernel, not the factor: nngp_model_build_rows / nngp_model_append reset it)
 }
 
 int nngp_model_factor_buffers(nngp_model* m, float** a32, int64_t* ld, float** dinv) {
@@ -1788,6 +1798,7 @@ static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t
         a.row_begin = 0; a.row_end = n; a.sym = 1;
         a.ld64 = a.ld32 = np;
         a.nngp64 = m->kaux64;
+        a.no_comp = 1;  // the same bits as when the fit's own build writes it (nngp_model_build_rows)
         NNGP_TRY(launch_kernel_build(a, m->arch, s));
         NNGP_TRY(launch_zero_pad_f64(m->kaux64, np, n, np, s));
         m->aux_ready = true;

@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
 //   5  (also) 1 = old level-1 variance formula (full float64 residual + preconditioned remainder)
 //   5  (also) 50..57 int8 residual path (api.hip: use_i8s, ensure_i8s); round 4: 58 = five digit planes of z instead of three rounded ones;
 //      59 = row statistics and float32 copy in passes of their own instead of the fused combination; 60 = K chunks of 16384 always;
-//      61 = the factor's inverted blocks built in line (not beside the first predict's cross-kernel build); 62 = digit planes of K row by row; 63 = per-layer ReLU recursion in the kernel build (no composite map); 64 = seven z planes in FINE products
+//      61 = the factor's inverted blocks built in line (not beside the first predict's cross-kernel build); 62 = digit planes of K row by row; 63 = per-layer ReLU recursion in the kernel build (no composite map); 64 = seven z planes in FINE products; 65 = an NTK model's NNGP kernel always in a build of its own
 //   0  (also) 32 = alpha CG runs in stream order inside nngp_model_solve, early-stopped (resumed by whoever needs alpha itself)
 //   8  round 4, grouped Cholesky (set BEFORE the model is created): bit 1 = the schedule with the panel solves off the update stream
 //      (potrf_lookahead_grouped_v4; needs its extra streams); with it: 2 = bulk panel solves on the panel stream itself; 4 = early part
@@ -106,6 +106,7 @@ struct BuildArgs {
     double diag_add_ntk32;
     int lower32;        // 1: float32 outputs only get the lower triangle (factorisation input)
     const double* comp; // set by launch_kernel_build itself: the composite ReLU map's table (kernel_build.hip), or NULL
+    int no_comp;        // 1: keep the per-layer recursion (an NTK model's NNGP kernel: bit-identical whether it comes from the fit's own build or a build of its own)
 };
 int launch_row_sqnorm(const double* x, int64_t n, int d, double* q, hipStream_t s);
 int launch_diag_from_q(const double* q, int64_t n, const ArchDev& arch, double* dn, double* dt, hipStream_t s);

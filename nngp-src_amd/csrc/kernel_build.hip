@@ -771,7 +771,7 @@ static const double* comp_table(const ArchDev& arch) {
 int launch_kernel_build(const BuildArgs& a_in, const ArchDev& arch, hipStream_t s) {
     BuildArgs a = a_in;
     // NNGP outputs only, no biases, >= 2 ReLU layers: the composite map (debug key 5 = 63: the per-layer recursion)
-    a.comp = (a.ntk64 == nullptr && a.ntk32 == nullptr && NNGP_KNOB(5) != 63) ? comp_table(arch) : nullptr;
+    a.comp = (a.ntk64 == nullptr && a.ntk32 == nullptr && !a.no_comp && NNGP_KNOB(5) != 63) ? comp_table(arch) : nullptr;
     const int64_t rows = a.row_end - a.row_begin;
     if (rows <= 0 || a.n2 <= 0) return 0;
     NNGP_REQUIRE(a.d > 0, "kernel_build: d must be positive");
