@@ -300,8 +300,8 @@ def launch_ranks(n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg3 on one GPU, cfg4 on several")
     ap.add_argument("--mode", default=os.environ.get("NNGP_DIST_MODE", "shard"), choices=["shard", "replicate", "grid2d", "shard32"],
                     help="multi-GPU layout (default: the north star's row-block shard + all-gather; grid2d: the 2-D block-cyclic "
