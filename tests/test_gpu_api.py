@@ -539,6 +539,33 @@ def test_digit_planes_cut_from_the_lower_triangle_are_the_row_cut_bit_for_bit(ge
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("get", ["nngp", "ntk"])
+def test_later_residuals_with_five_rounded_planes_against_seven_and_float64(get):
+    """Round 4 (late): the FINE int8 products -- later residuals of the correction sweeps, the NTK's W = Z K_dd (reference op: the
+    covariance of predict_fn(..., compute_cov=True), train.py:157-158) -- go on with z rounded to 40 bits below its row maximum
+    (five planes, written back: 25 plane products instead of 28).  An iterate good to ~1e-8 does not see 9e-13: variances against
+    seven planes (timing-knob key 5 = 64) and against the float64 pipe (key 5 = 50), NNGP at level 3 and NTK at its default."""
+    n, mt = 4300, 600   # np >= 4096 and >= 512 padded test rows: the FINE path
+    x, y = synth.synthetic_queries(n, 24, seed=61)
+    xt, _ = synth.synthetic_queries(mt, 24, seed=62)
+    model = GPModel(n, 24, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], get=get, diag_reg=1e-3, knobs=True).fit(x, y)
+    if get == "nngp":
+        model.set_refine(3)   # two correction sweeps: the second residual is a FINE product (level 2 has only the first, COARSE one)
+    out = {}
+    for key in (0, 64, 50):
+        model.debug_set(5, key)
+        model.residual_timer(True)
+        _, var = model.predict(xt, cov="diag")
+        launches, _, flops, ops = model.residual_timer_read()
+        out[key] = (np.asarray(var), launches, ops / flops if flops else 0.0)
+    model.debug_set(5, 0)
+    model.close()
+    assert out[50][1] == 0 and out[0][1] >= 2 and out[0][1] == out[64][1]      # float64 pipe: no int8 launches
+    assert out[0][2] < out[64][2] <= 28.0                                      # fewer plane products per launch on average
+    for key in (64, 50):
+        assert np.max(np.abs(out[0][0] - out[key][0]) / np.abs(out[key][0])) < 5e-9, key
+
+
 def test_int8_residual_path_against_the_float64_residual():
     """The level-1 variance with its residual product on the int8 pipe (exact digit planes, gemm_i8s.hip; reference op: the
     covariance of predict_fn(..., compute_cov=True), train.py:157-158) against the same predict with the float64 product
