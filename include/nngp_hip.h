@@ -339,6 +339,17 @@ int nngp_pool_select(const double* mean, int64_t m, int32_t ny, const double* va
  * float16 pipe from 256 rows and N = 8192 on).  L is the factor of float32(K) + reg I: compare against a triangular solve with
  * the factor itself (nngp_model_factor_buffers), not against the float64 kernel. */
 int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode, void* stream);
+/* Round 5: from 128 right-hand-side rows and N = 2048 on, each of those blocked solves is ONE persistent launch whose workgroups
+ * draw work items (128 x 128 tiles of the diagonal products and of the updates, 16-row split passes) from a ticket counter and wait
+ * on device counters for the items they depend on (csrc/trsm_tickets.hip).  The order of the tickets is fixed on the host, and the
+ * launch cannot hang if every item's dependencies hold LOWER tickets.  This entry point returns that table for a shape -- row_tiles
+ * tiles of 128 rows, block_cols block columns of 1024 (the last one tail_tiles <= 8 tiles of 128 wide), forward (0) or backward (1)
+ * solve, as scheduled for `workers` resident workgroups -- as four int32 per item {type | panels << 4, row tile, column tile or
+ * 16-row group, block column}; type 0 = split of an updated block, 1 = diagonal-product tile, 2 = split of a solved block,
+ * 3 = update tile (its `panels` finished block columns start at `block column` and go back in solve order).  Host memory, no GPU
+ * needed; items == NULL only counts.  tests/test_host.py replays the tables against the kernel's own wait conditions. */
+int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers,
+                           int32_t* items /* host, 4 * cap */, int64_t cap, int64_t* count /* host */);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,
                       int64_t n, void* stream);

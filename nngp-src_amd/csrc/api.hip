@@ -84,6 +84,8 @@ struct nngp_model {
     TriInv tri{};
     LookAhead* la = nullptr;
     SplitWork split{};
+    TrsmTickets* tk = nullptr;   // the blocked solves as one persistent launch each (trsm_tickets.hip); NULL: step-by-step launches
+    bool tk_failed = false;      // a launch gave up waiting (error word): the model stays on the step-by-step solves
     double diag_max = 0.0;
 
     // predict-side buffers (grown on demand when m > m_cap)
@@ -209,6 +211,7 @@ struct nngp_model {
         for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.rowpart); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
         dev_free(split.ldiag); dev_free(split.dfrag);
+        tk_destroy(tk);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
         dev_free(ainv64);
@@ -265,6 +268,10 @@ int ensure_predict_capacity(nngp_model* m, int64_t mt, bool need_ktd) {
             m->split.b_panels = (int)((triinv_block(m->np_cap) + m->split.k_cap - 1) / m->split.k_cap);
             NNGP_TRY(dev_alloc(&m->split.planes_b, (int64_t)(m->split.b_panels - 1) * m->split.col_stride + (m->split.mb_cap + 256) * m->split.k_cap * 4));
             NNGP_TRY(dev_alloc(&m->split.row_inv, m->split.mb_cap));
+            // ... and the persistent form of the blocked solves (no room for its workspace: the step-by-step form stays)
+            tk_destroy(m->tk);
+            m->tk = nullptr;
+            if (m->split.k_cap == 1024 && triinv_block(m->np_cap) == 1024) NNGP_TRY(tk_create(&m->tk, m->np_cap, m->split.mb_cap) < 0 ? -1 : 0);
         }
         m->m_cap = cap;
     }
@@ -591,12 +598,19 @@ int tri_join(nngp_model* m, hipStream_t s) {
     if (m->tri_stale) {
         if (m->ev_tri == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri, hipEventDisableTiming));
         NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
+        if (m->tk != nullptr && m->tri.bs == 1024) NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, s));
         NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, s));
         m->tri_stale = false;
         m->tri_pending = true;
         return 0;
     }
     if (m->tri_pending) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_tri, 0));
+    if (m->tk != nullptr && !tk_inverses_ready(m->tk) && m->tri.bs == 1024) {  // the workspace was rebuilt after the blocks were inverted
+        NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, s));
+        if (m->ev_tri == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri, hipEventDisableTiming));
+        NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, s));
+        m->tri_pending = true;
+    }
     return 0;
 }
 
@@ -608,6 +622,7 @@ int tri_fork(nngp_model* m, hipStream_t s) {
     NNGP_HIP_CHECK(hipEventRecord(m->ev_tri_fork, s));
     NNGP_HIP_CHECK(hipStreamWaitEvent(m->la->panel, m->ev_tri_fork, 0));
     NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, m->la->panel));
+    if (m->tk != nullptr && m->tri.bs == 1024) NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, m->la->panel));
     NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, m->la->panel));
     m->tri_stale = false;
     m->tri_pending = true;
@@ -621,6 +636,20 @@ int tri_fork(nngp_model* m, hipStream_t s) {
 bool use_split_solves(const nngp_model* m, int64_t mp) {
     return m->split.l_ready && m->split.planes_b != nullptr && mp <= m->split.mb_cap && m->tri.bs % m->split.k_cap == 0 &&
            m->tri.bs / m->split.k_cap <= m->split.b_panels && m->tri.bs <= 2048 && NNGP_KNOB(7) == 0 && mp >= 256 && mp * m->np >= 7000000;
+}
+
+// one persistent, ticket-ordered launch per solve (trsm_tickets.hip) instead of np / 1024 steps of three launches (debug key 9 = 16: the steps)
+bool use_tickets(const nngp_model* m, int64_t mp) {
+    return !m->tk_failed && m->tri.bs == 1024 && tk_usable(m->tk, mp, m->np) && NNGP_KNOB(9) != 16;
+}
+
+// a persistent solve that gave up waiting left its error word behind: report it once, and keep the model off that path
+int tickets_check(nngp_model* m, bool wait) {
+    const int e = tk_poll_error(m->tk, wait);
+    if (e == 0) return 0;
+    m->tk_failed = true;
+    set_error("a persistent blocked solve gave up waiting for a dependency (error word 0x%x): its results are invalid; the model now uses the step-by-step solves", e);
+    return -6;
 }
 
 // event pair around one blocked solve of mp right-hand sides (np^2 mp flops: a triangular matrix, multiply-add = 2)
@@ -647,6 +676,7 @@ static int apply_forward_untimed(nngp_model* m, int64_t mp, hipStream_t s);
 
 // b32 [mp, np] <- b32 L^-T   (rows are right-hand sides)
 int apply_forward_f32(nngp_model* m, int64_t mp, hipStream_t s) {
+    NNGP_TRY(tickets_check(m, false));
     NNGP_TRY(tri_join(m, s));
     int slot = -1;
     NNGP_TRY(trsm_timer_begin(m, mp, s, &slot));
@@ -660,8 +690,10 @@ static int apply_forward_untimed(nngp_model* m, int64_t mp, hipStream_t s) {
     m->split.solve_reserve = (m->gate_recorded && NNGP_KNOB(13) > 0) ? NNGP_KNOB(13) : 0;
     if (NNGP_KNOB(7) == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
         return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->ld, m->dinv, m->np, s);
-    if (use_split_solves(m, mp))
+    if (use_split_solves(m, mp)) {
+        if (use_tickets(m, mp)) return tk_solve(m->tk, m->b32, m->np, mp, m->np, m->split, false, s);
         return trsm_rlt_blocks_h3(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, m->split, s);
+    }
     return trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, s);
 }
 
@@ -688,7 +720,9 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     if (use_split_solves(m, mp)) NNGP_TRY(ensure_lt_split(m, s));
     int slot = -1;
     NNGP_TRY(trsm_timer_begin(m, mp, s, &slot));
-    if (use_split_solves(m, mp))
+    if (use_split_solves(m, mp) && use_tickets(m, mp))
+        NNGP_TRY(tk_solve(m->tk, m->b32, m->np, mp, m->np, m->split, true, s));
+    else if (use_split_solves(m, mp))
         NNGP_TRY(trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt_ready ? m->lt32 : nullptr, m->np, m->tri, m->np, m->trsm_tmp, m->split, s));
     else
         NNGP_TRY(trsm_rut_blocks_f32(m->b32, m->np, mp, m->lt32, m->np, m->tri, m->np, m->trsm_tmp, s));
@@ -1453,6 +1487,7 @@ int nngp_model_update_timer_bytes(nngp_model* m, double* bytes_total) {
 
 int nngp_model_info(nngp_model* m, nngp_fit_info* info) {
     NNGP_REQUIRE(m != nullptr && info != nullptr, "model_info: NULL argument");
+    NNGP_TRY(tickets_check(m, true));
     NNGP_TRY(run_pending_solve(m, nullptr, false));
     int32_t cl = 0;
     if (m->factored) NNGP_HIP_CHECK(hipMemcpy(&cl, m->clamped, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1934,6 +1969,11 @@ int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode,
     }
     NNGP_HIP_CHECK(hipMemcpy2DAsync(b, sizeof(float) * n, m->b32, sizeof(float) * np, sizeof(float) * n, rows, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t* items,
+                           int64_t cap, int64_t* count) {
+    return tk_order_export(row_tiles, block_cols, tail_tiles, backward, workers, items, cap, count);
 }
 
 int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream) {

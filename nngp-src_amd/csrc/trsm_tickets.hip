@@ -1,0 +1,811 @@
+// One persistent kernel per blocked triangular solve of the posterior (the cho_solve inside predict_fn,
+// reference call site train.py:157-158):  B[m, np] <- B L^-T (forward) or B L^-1 (backward), float32-grade, on the float16
+// matrix pipe.  Rounds 1-4 ran each solve as np / 1024 dependent steps of {float32 diagonal product, row split, update launch}:
+// ~100 launches whose update rounds were 6-100 % full (DESIGN_NOTES R4-Z).  Here the whole solve is ONE launch whose workgroups
+// draw work items from a ticket counter, in an order fixed on the host:
+//
+//   SB(r, J, q)  split copy (hi + lo float16, one power-of-two scale per row) of 16 rows of the fully updated block B_J[r]
+//   D (r, c)     X[r, c] = sum_k B_J[r, k] Linv_J[c, k]      128 x 128 tile of the diagonal product, K <= 1024, triangular
+//   SX(r, J, q)  split copy of 16 rows of X_J[r]
+//   U (r, c, P)  B[r, c] -= sum_{J in P} X_J[r] L[c, J]^T     128 x 128 tile, K = 1024 |P|, up to four finished block columns per pass
+//
+// r = tile of 128 right-hand-side rows, c = tile of 128 columns, J = block column of 1024.  Different r never interact, so the
+// dependencies are four monotone counters per r (device memory, zeroed before the launch): updates applied to tile (r, c),
+// split rows of B_J[r] written, diagonal tiles of X_J[r] done, split rows of X_J[r] written.
+//
+// Hang safety by construction: an item waits only for items with a LOWER ticket (the host's list scheduler starts an item only
+// after the items it depends on have finished in its simulation, so they precede it in the table).  Every lower ticket is held by a
+// workgroup that is already running or has finished, so the lowest unfinished ticket can always proceed: no co-residency
+// assumption, any grid size.  Every spin loop is bounded in wall-clock time (s_memrealtime); on expiry the workgroup sets the
+// error word and leaves, every other workgroup sees the word at its next poll or ticket and leaves too, and the host reports
+// NNGP_ERR through nngp_last_error at its next call -- a bug costs a red test, not the box.
+//
+// Visibility between workgroups (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): producer =
+// write-through (sc1) stores, every wave s_waitcnt vmcnt(0), workgroup barrier, one lane: agent-scope release fence, vmcnt(0),
+// agent-scope atomic add on the counter; consumer = one wave polls with agent-scope relaxed loads, agent-scope acquire fence,
+// vmcnt(0), workgroup barrier, then plain loads and LDS-DMA.
+//
+// Tile arithmetic: the 128 x 128 form of the split-float16 product (256 threads = 4 waves 2 x 2, wave sub-tile 64 x 64 as 4 x 4
+// accumulators of v_mfma_f32_16x16x32_f16 with swapped operands, 2 x 32 KB LDS stages by global_load_lds_dwordx4, one barrier per
+// stage), two workgroups per compute unit so that one's waits, epilogue and split items run under the other's MFMAs.
+#include <stdlib.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "common.h"
+
+namespace nngp {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int TT = 128;                  // tile edge
+constexpr int TROW = 128;                // bytes per LDS row: 32 hi + 32 lo halfs
+constexpr int TSTAGE = 2 * TT * TROW;    // A rows + B rows: 32 KB
+constexpr int64_t kLdp = 4096;           // bytes per split row (1024 k x 4 bytes), every plane buffer
+constexpr int kBs = 1024;                // block-column width
+constexpr int kQ = 8;                    // split items per (r, J): 16 rows each
+
+enum { IT_SB = 0, IT_D = 1, IT_SX = 2, IT_U = 3 };
+enum { SY_TICKET = 0, SY_ERROR = 1, SY_COUNTERS = 16 };
+
+struct TkParams {
+    float* b;                 // right-hand sides [mt * 128, np], row stride ldb
+    int64_t ldb;
+    const char* lplanes;      // split copy of L by block column (forward) / of L^T by block row (backward)
+    int64_t l_stride;         // bytes between block columns
+    const char* dinv_s;       // split copies of the inverted diagonal blocks, [nb][1024 rows][4096 bytes]
+    const float* dinv_iscale; // [nb] 1 / scale of each
+    char* planes_x;           // [nb][m_cap][4096]
+    char* planes_d;
+    int64_t p_stride;         // bytes between block columns of planes_x / planes_d
+    float* rinv_x;            // [nb][m_cap]
+    float* rinv_d;
+    int64_t r_stride;
+    const int4* items;
+    int n_items;
+    int* sync;
+    int mt, nb, ctiles, tail_ct;
+    float l_iscale;           // 1 / scale of the factor's split copy
+    int backward;
+    unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
+    unsigned spin_max;              // ... and in polls (a second bound that does not depend on a clock)
+};
+
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte / 4-byte write-through stores (sc1): the bytes leave the XCD's L2 with the store, so the release fence behind them finds
+// nothing to write back ("publish-large" in the guide's price list).  Inline assembly, because HIP has no 128-bit store with a
+// cache policy -- and therefore with the wait states hipcc would insert itself: a VALU write to the data registers of a VMEM
+// store of more than 64 bits needs them (CDNA3 ISA, manually inserted wait states), and hipcc, which does not know that the
+// statement is a store, reuses those registers at once (first runs of this kernel: split rows with values of the NEXT row in them).
+__device__ __forceinline__ void st16_wt(void* p, f32x4v v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st16h_wt(void* p, h8 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st4_wt(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * TSTAGE];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
+    int& s_word = *reinterpret_cast<int*>(smem);                     // ticket / wait status: only touched between items
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = __builtin_amdgcn_readfirstlane(wave >> 1);
+    const int wn = __builtin_amdgcn_readfirstlane(wave & 1);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int l3 = lane >> 3;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const unsigned lane_off = (unsigned)l3 * (unsigned)kLdp + (((lane & 7) ^ ((4 * (wv & 1) + (l3 >> 1)) & 7)) << 4);
+    const unsigned frag_hi = (unsigned)r16 * TROW + (((unsigned)q4 ^ ((unsigned)r16 >> 1)) << 4);
+    const unsigned frag_lo = frag_hi ^ 64u;
+    int* const sync = P.sync;
+    const int mt = P.mt, nb = P.nb;
+    int* const cnt_xd = sync + SY_COUNTERS;           // [mt][nb] diagonal tiles of X_J[r] finished
+    int* const cnt_xs = cnt_xd + mt * nb;             // [mt][nb] split items of X_J[r] finished
+    int* const cnt_bs = cnt_xs + mt * nb;             // [mt][nb] split items of B_J[r] finished
+    int* const cnt_up = cnt_bs + mt * nb;             // [mt][ctiles] block columns applied to tile (r, c)
+
+    // The loop holds exactly ONE block that only thread 0 executes (publish + next ticket, at its bottom, between two workgroup
+    // barriers).  With the ticket fetch in a block of its own at the top, hipcc threaded thread 0's path from the publish block
+    // across the back edge into the fetch block, which made the rest of the loop an INNER loop that the other 255 threads never leave:
+    // lane 0 of wave 0 waited for its wave's reconvergence, nothing was ever published (first GPU run of this kernel: every workgroup
+    // holding its first ticket, no counter moving).
+    if (tid == 0) s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
+    __syncthreads();
+    int ticket = __builtin_amdgcn_readfirstlane(s_word);
+    __syncthreads();
+    while (ticket < P.n_items) {
+        const int4 it = P.items[ticket];
+        const int type = __builtin_amdgcn_readfirstlane(it.x & 15), npan = __builtin_amdgcn_readfirstlane((it.x >> 4) & 15);
+        const int r = __builtin_amdgcn_readfirstlane(it.y), cq = __builtin_amdgcn_readfirstlane(it.z),
+                  J = __builtin_amdgcn_readfirstlane(it.w);
+        // block column of a tile, its tile count, panels applied to it when it is complete
+        const int Jc = (type == IT_U || type == IT_D) ? cq / 8 : J;
+        const int ct_j = (Jc == nb - 1) ? P.tail_ct : 8;
+
+        // ---- dependencies: wave 0 polls, one counter per lane ----
+        if (wave == 0) {
+            const int* addr = sync + SY_ERROR;
+            int need = 0;
+            bool active = false;
+            if (type == IT_U) {
+                // the latest block column of the item is split; the tile has received everything before the item's earliest one
+                const int first_in_time = P.backward ? J + npan - 1 : J - npan + 1;
+                if (lane == 0) { addr = cnt_xs + r * nb + J; need = kQ; active = true; }
+                if (lane == 1) { addr = cnt_up + r * P.ctiles + cq; need = P.backward ? nb - 1 - first_in_time : first_in_time; active = true; }
+            } else if (type == IT_D) {
+                if (lane == 0) { addr = cnt_bs + r * nb + Jc; need = kQ; active = true; }
+            } else if (type == IT_SX) {
+                if (lane == 0) { addr = cnt_xd + r * nb + J; need = ct_j; active = true; }
+            } else {  // IT_SB: every tile of the block has received all its updates
+                if (lane < ct_j) { addr = cnt_up + r * P.ctiles + J * 8 + lane; need = P.backward ? nb - 1 - J : J; active = true; }
+            }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int status = 0;
+            for (unsigned spins = 0;; ++spins) {
+                const int v = active ? ld_agent(addr) : need;
+                const int e = lane == 63 ? ld_agent(sync + SY_ERROR) : 0;
+                if (__any(e != 0)) { status = 1; break; }
+                if (__all(v >= need)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > P.spin_ticks || spins > P.spin_max) {
+                    if (lane == 0) atomicOr(sync + SY_ERROR, 0x100 | type);
+                    status = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) s_word = status;
+        }
+        __syncthreads();
+        const int status = __builtin_amdgcn_readfirstlane(s_word);
+        __syncthreads();
+        if (status != 0) break;
+
+        int* done_counter;
+        int done_add = 1;
+        if (type == IT_SB || type == IT_SX) {
+            // ---- split item: rows r*128 + cq*16 + wave*4 + i, columns of block J ----
+            const bool is_x = type == IT_SX;
+            char* planes = (is_x ? P.planes_x : P.planes_d) + (int64_t)J * P.p_stride;
+            float* rinv = (is_x ? P.rinv_x : P.rinv_d) + (int64_t)J * P.r_stride;
+            const int width = ct_j * TT;
+            const int row0 = r * TT + cq * 16 + wv * 4;
+            f32x4v v[4][2][2];
+            float mx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* src = P.b + (int64_t)(row0 + i) * P.ldb + (int64_t)J * kBs;
+                mx[i] = 0.0f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k0 = h * 512 + lane * 8;
+                    if (k0 < width) {
+                        v[i][h][0] = *reinterpret_cast<const f32x4v*>(src + k0);
+                        v[i][h][1] = *reinterpret_cast<const f32x4v*>(src + k0 + 4);
+                    } else {
+                        v[i][h][0] = v[i][h][1] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mx[i] = fmaxf(mx[i], fabsf(v[i][h][g][e]));
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], off));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int e2 = 0;
+                (void)frexpf(mx[i], &e2);  // mx = f * 2^e2, f in [0.5, 1): largest entry -> [2^13, 2^14)
+                const float sc = (mx[i] > 0.0f && mx[i] < 3.0e38f) ? ldexpf(1.0f, 14 - e2) : 1.0f;
+                if (lane == 0) st4_wt(rinv + row0 + i, 1.0f / sc);
+                char* drow = planes + (int64_t)(row0 + i) * kLdp;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k0 = h * 512 + lane * 8;
+                    if (k0 >= width) continue;
+                    h8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a = v[i][h][e >> 2][e & 3] * sc;
+                        const _Float16 hh = (_Float16)a;
+                        hi[e] = hh;
+                        lo[e] = (_Float16)(a - (float)hh);
+                    }
+                    char* dst = drow + (k0 >> 5) * 128 + (k0 & 31) * 2;
+                    st16h_wt(dst, hi);
+                    st16h_wt(dst + 64, lo);
+                }
+            }
+            done_counter = (is_x ? cnt_xs : cnt_bs) + r * nb + J;
+        } else {
+            // ---- tile item ----
+            const bool is_u = type == IT_U;
+            const int cl = cq - Jc * 8;  // tile inside its block column
+            // operands: k-blocks kb_hi down to kb_lo of every panel; panel p lies a_pst / b_pst bytes from panel p - 1
+            int kb_lo, kb_hi;
+            const char* pa;
+            const char* pb;
+            int64_t a_pst = 0, b_pst = 0;
+            if (is_u) {
+                const int ct_p = (J == nb - 1) ? P.tail_ct : 8;  // (a tail panel is never grouped with others)
+                kb_lo = 0;
+                kb_hi = ct_p * 4 - 1;
+                pa = P.planes_x + (int64_t)J * P.p_stride + (int64_t)(r * TT) * kLdp;
+                pb = P.lplanes + (int64_t)J * P.l_stride + (int64_t)(cq * TT) * kLdp;
+                a_pst = P.backward ? P.p_stride : -P.p_stride;
+                b_pst = P.backward ? P.l_stride : -P.l_stride;
+            } else {
+                // forward: Linv lower (k <= column) -> k tiles 0 .. cl; backward: L^-T upper -> k tiles cl .. ct_j - 1
+                kb_lo = P.backward ? cl * 4 : 0;
+                kb_hi = P.backward ? ct_j * 4 - 1 : cl * 4 + 3;
+                pa = P.planes_d + (int64_t)Jc * P.p_stride + (int64_t)(r * TT) * kLdp;
+                pb = P.dinv_s + (int64_t)Jc * ((int64_t)kBs * kLdp) + (int64_t)(cl * TT) * kLdp;
+            }
+            const int nkp = kb_hi - kb_lo + 1;
+            const int nstage = nkp * (is_u ? npan : 1);
+            int cur_p = 0, cur_kb = kb_hi;
+            auto glds_stage = [&](int t) {  // the wave's 4 B pieces and 4 A pieces of stage t at the cursor; advances the cursor
+                const int64_t offa = (int64_t)cur_kb * 128 + (int64_t)cur_p * a_pst;
+                const int64_t offb = (int64_t)cur_kb * 128 + (int64_t)cur_p * b_pst;
+                if (--cur_kb < kb_lo) { cur_kb = kb_hi; ++cur_p; }
+                char* dst = smem + (t & 1) * TSTAGE;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int piece = e * 4 + wv;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(pb + offb + (int64_t)piece * 8 * kLdp + lane_off),
+                                                     (lds_void*)(dst + TT * TROW + piece * 1024), 16, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int piece = e * 4 + wv;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(pa + offa + (int64_t)piece * 8 * kLdp + lane_off),
+                                                     (lds_void*)(dst + piece * 1024), 16, 0, 0);
+                }
+            };
+            glds_stage(0);
+            // per-row scales of the A operand's panels (powers of two): rs[p][i] for the lane's rows 16 i + r16 of the wave's 64
+            const int row_base = r * TT + wm * 64;
+            float rs[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rs[p][i] = 1.0f;
+            if (is_u) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (p < npan) {
+                        const float* rv = P.rinv_x + (int64_t)(P.backward ? J + p : J - p) * P.r_stride + row_base + r16;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rs[p][i] = rv[16 * i];
+                    }
+            } else {
+                const float* rv = P.rinv_d + (int64_t)Jc * P.r_stride + row_base + r16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rs[0][i] = rv[16 * i];
+            }
+            // (the compiler waits for these loads where they are first used: behind the first stage's wait anyway)
+
+            f32x4v acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+            int next_bound = nkp, pcur = 0;
+            for (int t = 0; t < nstage; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own 8 pieces of stage t
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < nstage) glds_stage(t + 1);
+                const char* sa_ = smem + (t & 1) * TSTAGE;
+                const char* sb_ = sa_ + TT * TROW;
+                h8 bh[4], bl[4], ah[4], al[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rb = (wn * 64 + j * 16) * TROW;
+                    bh[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_hi);
+                    bl[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_lo);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rb = (wm * 64 + i * 16) * TROW;
+                    ah[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_hi);
+                    al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
+                }
+                if (t == next_bound) {
+                    // panel boundary: the sums so far carry panel pcur's row scales, the terms to come panel pcur + 1's
+                    // (ratios of powers of two: exact)
+                    next_bound += nkp;
+                    float f[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float a = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : rs[2][i];
+                        const float b = pcur == 0 ? rs[1][i] : pcur == 1 ? rs[2][i] : rs[3][i];
+                        f[i] = a / b;
+                    }
+                    ++pcur;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][e] *= f[i];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- epilogue: acc[i][j][e] = tile(wm*64 + 16 i + r16, wn*64 + 16 j + 4 q4 + e) ----
+            float fs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float last = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : pcur == 2 ? rs[2][i] : rs[3][i];
+                fs[i] = last * (is_u ? -P.l_iscale : P.dinv_iscale[Jc]);
+            }
+            const unsigned voff = ((unsigned)r16 * (unsigned)P.ldb + 4u * (unsigned)q4) * 4u;
+            char* cw = reinterpret_cast<char*>(P.b + (int64_t)(row_base)*P.ldb + (int64_t)cq * TT + wn * 64);
+            const int64_t band = (int64_t)16 * P.ldb * 4;
+            if (is_u) {
+                f32x4v cold[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cold[i][j] = *reinterpret_cast<const f32x4v*>(cw + i * band + voff + 64 * j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(fs[i], acc[i][j][e], cold[i][j][e]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] *= fs[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st16_wt(cw + i * band + voff + 64 * j, acc[i][j]);
+            if (is_u) {
+                done_counter = cnt_up + r * P.ctiles + cq;
+                done_add = npan;
+            } else {
+                done_counter = cnt_xd + r * nb + Jc;
+            }
+        }
+        // ---- publish: every wave's stores have left, then one lane releases and counts -- and takes the next ticket ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicAdd(done_counter, done_add);
+            s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
+        }
+        __syncthreads();
+        ticket = __builtin_amdgcn_readfirstlane(s_word);
+        __syncthreads();
+    }
+}
+
+// absolute maximum of each bs x bs block (bit pattern of a non-negative float orders like an unsigned)
+__global__ __launch_bounds__(256) void k_block_absmax(const float* __restrict__ a, int64_t per_block, unsigned* __restrict__ out) {
+    const float* p = a + (int64_t)blockIdx.y * per_block;
+    float mx = 0.0f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < per_block; i += (int64_t)gridDim.x * 1024) {
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(p + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[e]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f && mx < 3.0e38f) atomicMax(out + blockIdx.y, __float_as_uint(mx));
+}
+
+// split rows of every block with the block's own power-of-two scale (largest entry -> [2^13, 2^14)); iscale[b] = 1 / scale
+__global__ __launch_bounds__(256) void k_split_blocks(const float* __restrict__ a, int bs, const unsigned* __restrict__ amax,
+                                                      char* __restrict__ out, float* __restrict__ iscale) {
+    const int blk = blockIdx.y;
+    const float mx = __uint_as_float(amax[blk]);
+    int e2 = 0;
+    (void)frexpf(mx, &e2);
+    const float sc = mx > 0.0f ? ldexpf(1.0f, 14 - e2) : 1.0f;
+    const int k8 = bs / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) iscale[blk] = 1.0f / sc;
+    const int64_t rr = idx / k8;
+    const int c8 = (int)(idx % k8);
+    if (rr >= bs) return;
+    const f32x4v* src = reinterpret_cast<const f32x4v*>(a + (int64_t)blk * bs * bs + rr * bs + (int64_t)c8 * 8);
+    const f32x4v v0 = src[0], v1 = src[1];
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (e < 4 ? v0[e] : v1[e - 4]) * sc;
+        const _Float16 h = (_Float16)x;
+        hi[e] = h;
+        lo[e] = (_Float16)(x - (float)h);
+    }
+    char* dst = out + (int64_t)blk * ((int64_t)kBs * kLdp) + rr * kLdp + (int64_t)(c8 >> 2) * 128 + (c8 & 3) * 16;
+    *reinterpret_cast<h8*>(dst) = hi;
+    *reinterpret_cast<h8*>(dst + 64) = lo;
+}
+
+// ---- host: the ticket order ----
+// List scheduling on `workers` simulated workgroups with rough item durations: an item enters the table when the simulation starts
+// it, i.e. after everything it depends on has FINISHED there -- so every dependency has a lower ticket whatever the real timing is.
+// Priority: earliest deadline first, the deadline of an item being the block column it feeds (diagonal chain items before the
+// updates of the next block column).  A tile that comes up for an update takes every finished block column that is waiting for
+// it, up to four (K = 4096 in one pass over the tile): deep K where the chip is throughput-bound, single panels near the chain.
+struct SimItem {
+    int type, r, cq, J, npan;
+};
+
+void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std::vector<int4>& out) {
+    const int ctiles = (nb - 1) * 8 + tail_ct;
+    auto ct_of = [&](int J) { return J == nb - 1 ? tail_ct : 8; };
+    // position of block column J in solve order (0 = solved first) and back
+    auto pos_of = [&](int J) { return backward ? nb - 1 - J : J; };
+    auto blk_at = [&](int pos) { return backward ? nb - 1 - pos : pos; };
+    const double t_split = 5.0, t_tile0 = 8.0, t_stage = 0.6;
+    int max_pan = 4;
+    if (const char* e = getenv("NNGP_TK_MAXPAN")) max_pan = std::max(1, std::min(4, atoi(e)));  // development aid
+    struct Ready {
+        int key, c, r, type, J;  // J: block (S, D) ; for U: unused
+        bool operator<(const Ready& o) const {  // priority_queue: largest first -> invert
+            if (key != o.key) return key > o.key;
+            if (c != o.c) return c > o.c;
+            return r > o.r;
+        }
+    };
+    struct Done {
+        double t;
+        int type, r, cq, J, npan;
+        bool operator<(const Done& o) const { return t > o.t; }
+    };
+    std::priority_queue<Ready> ready;
+    std::priority_queue<Done> running;
+    std::vector<int> up((size_t)mt * ctiles, 0);      // panels applied (in solve order positions)
+    std::vector<char> busy((size_t)mt * ctiles, 0);   // an update of the tile is running or queued
+    std::vector<int> xs((size_t)mt * nb, 0), xd((size_t)mt * nb, 0), bs((size_t)mt * nb, 0), tiles_final((size_t)mt * nb, 0);
+    std::vector<int> xready((size_t)mt, 0);           // positions [0, xready[r]) have their split X
+    // a tile (r, c) in block position pc needs panels at positions 0 .. pc - 1, in order
+    auto queue_tile = [&](int r, int c) {
+        const size_t id = (size_t)r * ctiles + c;
+        const int pc = pos_of(c / 8);
+        if (busy[id] || up[id] >= pc || up[id] >= xready[r]) return;
+        busy[id] = 1;
+        ready.push(Ready{2 * pc - 1, c, r, IT_U, 0});
+    };
+    auto push_block_items = [&](int type, int r, int J) {
+        const int n = type == IT_D ? ct_of(J) : kQ;
+        for (int i = 0; i < n; ++i) ready.push(Ready{2 * pos_of(J), type == IT_D ? J * 8 + i : i, r, type, J});
+    };
+    for (int r = 0; r < mt; ++r) push_block_items(IT_SB, r, blk_at(0));
+    int free_workers = workers;
+    double now = 0.0;
+    size_t total = 0;
+    for (int J = 0; J < nb; ++J) total += (size_t)mt * (2 * kQ + ct_of(J));
+    out.clear();
+    for (;;) {
+        while (free_workers > 0 && !ready.empty()) {
+            const Ready it = ready.top();
+            ready.pop();
+            int4 rec;
+            double dur;
+            Done d{};
+            if (it.type == IT_U) {
+                const size_t id = (size_t)it.r * ctiles + it.c;
+                const int pc = pos_of(it.c / 8);
+                const int p0 = up[id];
+                int avail = std::min(pc, xready[it.r]) - p0;
+                if (avail > max_pan) avail = max_pan;
+                // a tail-width panel (the last block column: first in the backward order) goes alone
+                if (backward && tail_ct != 8 && p0 == 0) avail = 1;
+                const int plast = p0 + avail - 1;  // latest panel of the item in solve order = first processed
+                rec = int4{IT_U | (avail << 4), it.r, it.c, blk_at(plast)};
+                dur = t_tile0 + t_stage * 32 * avail;
+                d = Done{now + dur, IT_U, it.r, it.c, 0, avail};
+            } else {
+                rec = int4{it.type | (1 << 4), it.r, it.c, it.J};
+                if (it.type == IT_D) {
+                    const int cl = it.c - it.J * 8;
+                    const int nk = backward ? (ct_of(it.J) - cl) * 4 : (cl + 1) * 4;
+                    dur = t_tile0 + t_stage * nk;
+                } else {
+                    dur = t_split;
+                }
+                d = Done{now + dur, it.type, it.r, it.c, it.J, 1};
+            }
+            out.push_back(rec);
+            running.push(d);
+            --free_workers;
+        }
+        if (running.empty()) break;
+        const Done d = running.top();
+        running.pop();
+        now = d.t;
+        ++free_workers;
+        const int r = d.r;
+        if (d.type == IT_SB) {
+            if (++bs[(size_t)r * nb + d.J] == kQ) push_block_items(IT_D, r, d.J);
+        } else if (d.type == IT_D) {
+            if (++xd[(size_t)r * nb + d.J] == ct_of(d.J)) push_block_items(IT_SX, r, d.J);
+        } else if (d.type == IT_SX) {
+            if (++xs[(size_t)r * nb + d.J] == kQ) {
+                xready[r] = pos_of(d.J) + 1;
+                for (int c = 0; c < ctiles; ++c)
+                    if (pos_of(c / 8) > pos_of(d.J)) queue_tile(r, c);
+            }
+        } else {
+            const size_t id = (size_t)r * ctiles + d.cq;
+            up[id] += d.npan;
+            busy[id] = 0;
+            const int Jt = d.cq / 8;
+            if (up[id] == pos_of(Jt)) {
+                if (++tiles_final[(size_t)r * nb + Jt] == ct_of(Jt)) push_block_items(IT_SB, r, Jt);
+            } else {
+                queue_tile(r, d.cq);
+            }
+        }
+    }
+    (void)total;
+}
+
+}  // namespace
+
+struct TrsmTickets {
+    int64_t m_cap = 0, np_cap = 0, nb_cap = 0;
+    char* planes_x = nullptr;
+    char* planes_d = nullptr;
+    float* rinv_x = nullptr;
+    float* rinv_d = nullptr;
+    char* xinv_s = nullptr;
+    char* tinv_s = nullptr;
+    float* inv_iscale = nullptr;  // [2][nb_cap]: forward blocks, backward blocks
+    unsigned* amax = nullptr;     // [2][nb_cap]
+    int* sync = nullptr;
+    int64_t sync_ints = 0;
+    int4* items[2] = {nullptr, nullptr};
+    int64_t items_cap = 0;
+    int n_items[2] = {0, 0};
+    int key_mt = 0, key_nb = 0, key_tail = 0;
+    std::vector<int4> host_items[2];
+    int* host_err = nullptr;      // pinned: error word of the last launches
+    hipEvent_t ev_err = nullptr;
+    bool err_pending = false;
+    bool inv_ready = false;
+    int workers = 512;
+};
+
+static int64_t tk_items_bound(int64_t mt, int64_t nb) { return mt * (8 * nb * (nb - 1) / 2 + 24 * nb) + 64; }
+
+void tk_destroy(TrsmTickets* tk) {
+    if (tk == nullptr) return;
+    (void)hipFree(tk->planes_x); (void)hipFree(tk->planes_d); (void)hipFree(tk->rinv_x); (void)hipFree(tk->rinv_d);
+    (void)hipFree(tk->xinv_s); (void)hipFree(tk->tinv_s); (void)hipFree(tk->inv_iscale); (void)hipFree(tk->amax);
+    (void)hipFree(tk->sync); (void)hipFree(tk->items[0]); (void)hipFree(tk->items[1]);
+    if (tk->host_err) (void)hipHostFree(tk->host_err);
+    if (tk->ev_err) (void)hipEventDestroy(tk->ev_err);
+    delete tk;
+}
+
+// Buffers for right-hand-side blocks of up to m_cap rows against a factor of up to np_cap columns.  Returns 1 (and leaves *out NULL)
+// when the device has no room: the caller keeps the step-by-step solves.
+int tk_create(TrsmTickets** out, int64_t np_cap, int64_t m_cap) {
+    *out = nullptr;
+    if (np_cap < 2 * kBs || m_cap < TT || m_cap > 64 * TT) return 1;
+    TrsmTickets* tk = new (std::nothrow) TrsmTickets();
+    NNGP_REQUIRE(tk != nullptr, "tk_create: out of host memory");
+    tk->m_cap = round_up(m_cap, TT);
+    tk->np_cap = np_cap;
+    tk->nb_cap = (np_cap + kBs - 1) / kBs;
+    const int64_t nb = tk->nb_cap, mt = tk->m_cap / TT;
+    tk->sync_ints = SY_COUNTERS + 3 * mt * nb + mt * nb * 8;
+    tk->items_cap = tk_items_bound(mt, nb);
+    bool ok = true;
+    auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
+    A((void**)&tk->planes_x, (size_t)nb * tk->m_cap * kLdp);
+    A((void**)&tk->planes_d, (size_t)nb * tk->m_cap * kLdp);
+    A((void**)&tk->rinv_x, sizeof(float) * nb * tk->m_cap);
+    A((void**)&tk->rinv_d, sizeof(float) * nb * tk->m_cap);
+    A((void**)&tk->xinv_s, (size_t)nb * kBs * kLdp);
+    A((void**)&tk->tinv_s, (size_t)nb * kBs * kLdp);
+    A((void**)&tk->inv_iscale, sizeof(float) * 2 * nb);
+    A((void**)&tk->amax, sizeof(unsigned) * 2 * nb);
+    A((void**)&tk->sync, sizeof(int) * tk->sync_ints);
+    A((void**)&tk->items[0], sizeof(int4) * tk->items_cap);
+    A((void**)&tk->items[1], sizeof(int4) * tk->items_cap);
+    if (ok && hipHostMalloc(reinterpret_cast<void**>(&tk->host_err), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) ok = false;
+    if (ok && hipEventCreateWithFlags(&tk->ev_err, hipEventDisableTiming) != hipSuccess) ok = false;
+    if (!ok) {
+        (void)hipGetLastError();
+        tk_destroy(tk);
+        return 1;
+    }
+    tk->host_err[0] = tk->host_err[1] = 0;
+    int dev = 0, count = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && count > 0)
+        tk->workers = 2 * count;
+    *out = tk;
+    return 0;
+}
+
+// split copies of the inverted diagonal blocks (after triinv_build, on the same stream)
+int tk_prepare_inverses(TrsmTickets* tk, const TriInv& ti, int64_t np, hipStream_t s) {
+    NNGP_REQUIRE(tk != nullptr && ti.bs == kBs && np <= tk->np_cap, "tk_prepare_inverses: bad arguments");
+    const int nb = (int)((np + kBs - 1) / kBs);
+    NNGP_HIP_CHECK(hipMemsetAsync(tk->amax, 0, sizeof(unsigned) * 2 * tk->nb_cap, s));
+    const dim3 g1(64, (unsigned)nb), g2((unsigned)((int64_t)kBs * (kBs / 8) / 256), (unsigned)nb);
+    hipLaunchKernelGGL(k_block_absmax, g1, dim3(256), 0, s, ti.xinv, (int64_t)kBs * kBs, tk->amax);
+    hipLaunchKernelGGL(k_block_absmax, g1, dim3(256), 0, s, ti.tinv, (int64_t)kBs * kBs, tk->amax + tk->nb_cap);
+    hipLaunchKernelGGL(k_split_blocks, g2, dim3(256), 0, s, ti.xinv, kBs, tk->amax, tk->xinv_s, tk->inv_iscale);
+    hipLaunchKernelGGL(k_split_blocks, g2, dim3(256), 0, s, ti.tinv, kBs, tk->amax + tk->nb_cap, tk->tinv_s, tk->inv_iscale + tk->nb_cap);
+    NNGP_HIP_CHECK(hipGetLastError());
+    tk->inv_ready = true;
+    return 0;
+}
+
+// the ticket table of a shape, four ints per item {type | panels << 4, r, c or q, J}, for the host-side proof that every item's
+// dependencies hold lower tickets (tests/test_host.py)
+int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int32_t* out, int64_t cap, int64_t* count) {
+    NNGP_REQUIRE(mt >= 1 && nb >= 1 && tail_ct >= 1 && tail_ct <= 8 && workers >= 1 && count != nullptr, "trsm_ticket_order: bad shape");
+    std::vector<int4> items;
+    tk_build_order(mt, nb, tail_ct, backward != 0, workers, items);
+    *count = (int64_t)items.size();
+    if (out != nullptr) {
+        NNGP_REQUIRE((int64_t)items.size() <= cap, "trsm_ticket_order: %lld items, room for %lld", (long long)items.size(), (long long)cap);
+        for (size_t i = 0; i < items.size(); ++i) {
+            out[4 * i] = items[i].x; out[4 * i + 1] = items[i].y; out[4 * i + 2] = items[i].z; out[4 * i + 3] = items[i].w;
+        }
+    }
+    return 0;
+}
+
+bool tk_inverses_ready(const TrsmTickets* tk) { return tk != nullptr && tk->inv_ready; }
+void tk_invalidate_inverses(TrsmTickets* tk) { if (tk != nullptr) tk->inv_ready = false; }
+
+bool tk_usable(const TrsmTickets* tk, int64_t m, int64_t np) {
+    return tk != nullptr && tk->inv_ready && m % TT == 0 && m >= TT && m <= tk->m_cap && np % TT == 0 && np <= tk->np_cap && np >= 2 * kBs;
+}
+
+// B[m, np] <- B L^-T (backward = false; sw.planes) or B L^-1 (backward = true; sw.planes_t) in one launch
+int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, const SplitWork& sw, bool backward, hipStream_t s) {
+    NNGP_REQUIRE(tk_usable(tk, m, np), "tk_solve: not usable for m=%lld np=%lld", (long long)m, (long long)np);
+    NNGP_REQUIRE(sw.k_cap == kBs && (backward ? (sw.planes_t != nullptr && sw.lt_ready) : (sw.planes != nullptr && sw.l_ready)),
+                 "tk_solve: split copy of the factor not available");
+    NNGP_REQUIRE(ldb % 32 == 0 && ldb < (1LL << 26) && ((uintptr_t)b & 127) == 0, "tk_solve: right-hand sides must be 128-byte aligned rows");
+    const int mt = (int)(m / TT), nb = (int)((np + kBs - 1) / kBs);
+    const int tail_ct = (int)((np - (int64_t)(nb - 1) * kBs) / TT);
+    if (tk->key_mt != mt || tk->key_nb != nb || tk->key_tail != tail_ct) {
+        // a new shape (the first solve, or another batch size): the device may still read the old tables
+        NNGP_HIP_CHECK(hipDeviceSynchronize());
+        for (int dir = 0; dir < 2; ++dir) {
+            tk_build_order(mt, nb, tail_ct, dir == 1, tk->workers, tk->host_items[dir]);
+            NNGP_REQUIRE((int64_t)tk->host_items[dir].size() <= tk->items_cap, "tk_solve: item table overflow");
+            tk->n_items[dir] = (int)tk->host_items[dir].size();
+            NNGP_HIP_CHECK(hipMemcpy(tk->items[dir], tk->host_items[dir].data(), sizeof(int4) * tk->host_items[dir].size(), hipMemcpyHostToDevice));
+        }
+        tk->key_mt = mt; tk->key_nb = nb; tk->key_tail = tail_ct;
+    }
+    const int dir = backward ? 1 : 0;
+    TkParams P{};
+    P.b = b; P.ldb = ldb;
+    P.lplanes = backward ? sw.planes_t : sw.planes;
+    P.l_stride = sw.col_stride;
+    P.dinv_s = backward ? tk->tinv_s : tk->xinv_s;
+    P.dinv_iscale = tk->inv_iscale + (backward ? tk->nb_cap : 0);
+    P.planes_x = tk->planes_x; P.planes_d = tk->planes_d;
+    P.p_stride = tk->m_cap * kLdp;
+    P.rinv_x = tk->rinv_x; P.rinv_d = tk->rinv_d;
+    P.r_stride = tk->m_cap;
+    P.items = tk->items[dir];
+    P.n_items = tk->n_items[dir];
+    P.sync = tk->sync;
+    P.mt = mt; P.nb = nb; P.ctiles = (nb - 1) * 8 + tail_ct; P.tail_ct = tail_ct;
+    P.l_iscale = 1.0f / sw.scale;
+    P.backward = backward ? 1 : 0;
+    P.spin_ticks = 200000000ULL;  // 2 s
+    P.spin_max = 1u << 22;        // > 4 s of polls at ~1 us each
+    const int64_t used = SY_COUNTERS + 3LL * mt * nb + (int64_t)mt * P.ctiles;
+    NNGP_REQUIRE(used <= tk->sync_ints, "tk_solve: counter block overflow");
+    // the error word survives (sticky until the host has read it); ticket and counters restart
+    NNGP_HIP_CHECK(hipMemsetAsync(tk->sync, 0, sizeof(int) * SY_ERROR, s));
+    NNGP_HIP_CHECK(hipMemsetAsync(tk->sync + SY_ERROR + 1, 0, sizeof(int) * (used - SY_ERROR - 1), s));
+    int grid = tk->workers;
+    if (grid > P.n_items) grid = P.n_items;
+    hipLaunchKernelGGL(k_trsm_tickets, dim3((unsigned)grid), dim3(256), 0, s, P);
+    NNGP_HIP_CHECK(hipGetLastError());
+    NNGP_HIP_CHECK(hipMemcpyAsync(tk->host_err, tk->sync + SY_ERROR, sizeof(int), hipMemcpyDeviceToHost, s));
+    NNGP_HIP_CHECK(hipEventRecord(tk->ev_err, s));
+    tk->err_pending = true;
+    if (getenv("NNGP_TK_DUMP") != nullptr && !backward) {  // development aid: what the split rows of block column 0 hold after the solve
+        (void)hipDeviceSynchronize();
+        std::vector<_Float16> h(8 * 2048);
+        for (int row : {6, 7, 14, 15, 135}) {
+            if (hipMemcpy(h.data(), tk->planes_d + (int64_t)row * kLdp, kLdp, hipMemcpyDeviceToHost) != hipSuccess) break;
+            int bad = 0, firstbad = -1;
+            for (int kb = 0; kb < 32; ++kb)
+                for (int e = 0; e < 64; ++e) {
+                    const float v = (float)h[kb * 64 + e];
+                    if (!(fabsf(v) <= 16384.0f)) { ++bad; if (firstbad < 0) firstbad = kb * 64 + e; }
+                }
+            fprintf(stderr, "tk dump: planes_d[0] row %d: %d halfs out of range (first at %d); kb 0: %g %g, kb 24: %g %g %g %g, kb 31: %g\n", row, bad, firstbad,
+                    (double)(float)h[0], (double)(float)h[1], (double)(float)h[24 * 64], (double)(float)h[24 * 64 + 1], (double)(float)h[24 * 64 + 8], (double)(float)h[24 * 64 + 32], (double)(float)h[31 * 64]);
+        }
+    }
+    if (getenv("NNGP_TK_WATCH") != nullptr) {  // development aid: watch the launch from a second stream
+        hipStream_t w = nullptr;
+        std::vector<int> h((size_t)used);
+        if (hipStreamCreateWithFlags(&w, hipStreamNonBlocking) == hipSuccess) {
+            for (int it = 0; it < 40; ++it) {
+                if (hipEventQuery(tk->ev_err) == hipSuccess) { fprintf(stderr, "tk watch: launch finished (poll %d), error word 0x%x\n", it, tk->host_err[0]); break; }
+                (void)hipGetLastError();
+                usleep(250000);
+                if (hipMemcpyAsync(h.data(), tk->sync, sizeof(int) * (size_t)used, hipMemcpyDeviceToHost, w) != hipSuccess || hipStreamSynchronize(w) != hipSuccess) break;
+                long long sx = 0, sd = 0, sb = 0, su = 0;
+                for (int i = 0; i < mt * nb; ++i) { sd += h[SY_COUNTERS + i]; sx += h[SY_COUNTERS + mt * nb + i]; sb += h[SY_COUNTERS + 2 * mt * nb + i]; }
+                for (int i = 0; i < mt * P.ctiles; ++i) su += h[SY_COUNTERS + 3 * mt * nb + i];
+                fprintf(stderr, "tk watch %d: ticket %d / %d, error 0x%x, done: D %lld SX %lld SB %lld U-panels %lld\n", it, h[0], P.n_items, h[1], sd, sx, sb, su);
+            }
+            (void)hipStreamDestroy(w);
+        }
+    }
+    return 0;
+}
+
+// 0: no error seen (wait = false: only looks if the last launch has completed); otherwise the error word of a timed-out launch.
+// The word is cleared on the device once reported.
+int tk_poll_error(TrsmTickets* tk, bool wait) {
+    if (tk == nullptr || !tk->err_pending) return 0;
+    if (wait) {
+        if (hipEventSynchronize(tk->ev_err) != hipSuccess) return -1;
+    } else if (hipEventQuery(tk->ev_err) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    tk->err_pending = false;
+    const int e = tk->host_err[0];
+    if (e != 0) {
+        tk->host_err[0] = 0;
+        (void)hipMemset(tk->sync + SY_ERROR, 0, sizeof(int));
+    }
+    return e;
+}
+
+}  // namespace nngp

@@ -322,3 +322,76 @@ def test_active_train_cli_flags_and_split():
         assert (g is None and r is None) or np.array_equal(np.asarray(g), np.asarray(r))
     from nngp_src_amd.active import ActiveLearner
     assert ActiveLearner().biased_sample is True  # the reference's default
+
+
+def _replay_ticket_table(items, mt, nb, tail, backward):
+    """Walk a ticket table in order with the kernel's own counters (csrc/trsm_tickets.hip): an item may start only if the wait
+    condition the kernel polls already holds through items with LOWER tickets -- then no workgroup can ever wait on work nobody has
+    started -- and at the end every tile has received every block column exactly once, in order."""
+    ct = lambda J: tail if J == nb - 1 else 8
+    ctiles = (nb - 1) * 8 + tail
+    pos = (lambda J: nb - 1 - J) if backward else (lambda J: J)
+    xd = np.zeros((mt, nb), np.int64); xs = np.zeros((mt, nb), np.int64); bs = np.zeros((mt, nb), np.int64)
+    up = np.zeros((mt, ctiles), np.int64)
+    seen = set()
+    for t, (word, r, cq, J) in enumerate(items):
+        typ, npan = word & 15, (word >> 4) & 15
+        key = (typ, r, cq, J)
+        assert key not in seen, ("duplicate item", t, key)
+        seen.add(key)
+        assert 0 <= r < mt and 0 <= J < nb
+        if typ == 3:    # update tile: panels J, J -/+ 1, ... (latest first)
+            assert 1 <= npan <= 4 and 0 <= cq < ctiles
+            first = J + npan - 1 if backward else J - npan + 1      # earliest block column of the item
+            assert 0 <= first < nb
+            Jt = cq // 8
+            assert pos(J) < pos(Jt), ("an update from a block column that is not solved before its target", t)
+            assert xs[r, J] == 8, ("update before the split copy of its latest block column", t)
+            assert up[r, cq] == pos(first), ("update out of order", t, up[r, cq], pos(first))
+            if npan > 1:
+                assert ct(J) == 8 and ct(first) == 8, ("a tail-width panel grouped with others", t)
+            up[r, cq] += npan
+        elif typ == 1:  # diagonal-product tile
+            Jc = cq // 8
+            assert Jc == J and cq - 8 * J < ct(J)
+            assert bs[r, J] == 8, ("diagonal product before its operand is split", t)
+            xd[r, J] += 1
+        elif typ == 2:  # split of a solved block
+            assert 0 <= cq < 8 and xd[r, J] == ct(J), ("split of a block whose diagonal tiles are not all done", t)
+            xs[r, J] += 1
+        else:           # split of an updated block
+            assert typ == 0 and 0 <= cq < 8
+            for c in range(8 * J, 8 * J + ct(J)):
+                assert up[r, c] == pos(J), ("split of a block that has not received all its updates", t)
+            bs[r, J] += 1
+    for r in range(mt):
+        for J in range(nb):
+            assert xd[r, J] == ct(J) and xs[r, J] == 8 and bs[r, J] == 8
+            for c in range(8 * J, 8 * J + ct(J)):
+                assert up[r, c] == pos(J)
+    return len(items)
+
+
+@pytest.mark.parametrize("mt,nb,tail,workers", [(8, 32, 8, 512), (1, 2, 8, 512), (2, 3, 1, 16), (29, 11, 5, 512), (8, 8, 8, 512),
+                                                (3, 10, 8, 1), (8, 64, 8, 512), (5, 9, 3, 97)])
+def test_persistent_solve_ticket_tables_only_wait_on_lower_tickets(mt, nb, tail, workers):
+    """Round 5: the posterior's blocked triangular solves (reference: the cho_solve inside predict_fn, train.py:157-158) run as one
+    persistent launch each, whose workgroups take work items in ticket order and wait on device counters.  Hang freedom rests on ONE
+    property of the host-built table -- every item's dependencies hold lower tickets -- which this test proves for the bench shapes
+    (cfg3: 8 x 32, cfg4: 8 x 64, cfg2: 8 x 8, the forest run: 29 x 11 with a 640-wide tail), degenerate ones and odd worker counts,
+    forward and backward, by replaying the table against the kernel's wait conditions."""
+    lib = _lib.load()
+    for backward in (0, 1):
+        count = ctypes.c_int64(0)
+        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, None, 0, ctypes.byref(count)) == 0, lib.nngp_last_error()
+        buf = np.zeros((count.value, 4), np.int32)
+        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, buf.ctypes.data_as(ctypes.c_void_p), count.value,
+                                          ctypes.byref(count)) == 0, lib.nngp_last_error()
+        n = _replay_ticket_table([tuple(int(v) for v in row) for row in buf], mt, nb, tail, bool(backward))
+        assert n == count.value
+        # the table is a pure function of the shape: run-to-run bitwise reproducibility of the solves depends on it
+        buf2 = np.zeros_like(buf)
+        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, buf2.ctypes.data_as(ctypes.c_void_p), count.value,
+                                          ctypes.byref(count)) == 0
+        assert np.array_equal(buf, buf2)
+    assert lib.nngp_trsm_ticket_order(0, 4, 8, 0, 512, None, 0, ctypes.byref(count)) != 0
