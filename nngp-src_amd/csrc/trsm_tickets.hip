@@ -96,8 +96,19 @@ __device__ __forceinline__ void st4_wt(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * TSTAGE];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
+#ifdef NNGP_TIMING_KNOBS
+// timing study (knobs build): s_memrealtime ticks (10 ns) summed over all workgroups, per item type t = 0..3:
+// [t*4 + 0] wait + acquire, [t*4 + 1] body, [t*4 + 2] publish + next ticket, [t*4 + 3] items; [16] kernel ticks summed, [17] workgroups
+__device__ unsigned long long g_tk_stamps[20];
+#define TK_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define TK_NOW() 0ULL
+#endif
+
+constexpr int kRing = 4;  // operand stages in LDS: three in flight while one is multiplied
+
+__global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
+    __shared__ __attribute__((aligned(1024))) char smem[kRing * TSTAGE];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
     int& s_word = *reinterpret_cast<int*>(smem);                     // ticket / wait status: only touched between items
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -125,7 +136,12 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
     __syncthreads();
     int ticket = __builtin_amdgcn_readfirstlane(s_word);
     __syncthreads();
+#ifdef NNGP_TIMING_KNOBS
+    unsigned long long st[16] = {};
+    const unsigned long long st_k0 = TK_NOW();
+#endif
     while (ticket < P.n_items) {
+        const unsigned long long st_a = TK_NOW();
         const int4 it = P.items[ticket];
         const int type = __builtin_amdgcn_readfirstlane(it.x & 15), npan = __builtin_amdgcn_readfirstlane((it.x >> 4) & 15);
         const int r = __builtin_amdgcn_readfirstlane(it.y), cq = __builtin_amdgcn_readfirstlane(it.z),
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
         const int status = __builtin_amdgcn_readfirstlane(s_word);
         __syncthreads();
         if (status != 0) break;
+        const unsigned long long st_b = TK_NOW();
 
         int* done_counter;
         int done_add = 1;
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
                 const int64_t offa = (int64_t)cur_kb * 128 + (int64_t)cur_p * a_pst;
                 const int64_t offb = (int64_t)cur_kb * 128 + (int64_t)cur_p * b_pst;
                 if (--cur_kb < kb_lo) { cur_kb = kb_hi; ++cur_p; }
-                char* dst = smem + (t & 1) * TSTAGE;
+                char* dst = smem + (t & (kRing - 1)) * TSTAGE;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int piece = e * 4 + wv;
@@ -281,7 +298,12 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
                                                      (lds_void*)(dst + piece * 1024), 16, 0, 0);
                 }
             };
+            // The operands arrive HBM / L2-latency bound (~1.7 us a stage under load, against 0.4 us of MFMAs): stages t + 1 .. t + 3 are in
+            // flight while stage t is multiplied (the first form of this kernel, two workgroups per compute unit with two stages each, spent
+            // 2 us per stage: DESIGN_NOTES R5-T)
             glds_stage(0);
+            if (nstage > 1) glds_stage(1);
+            if (nstage > 2) glds_stage(2);
             // per-row scales of the A operand's panels (powers of two): rs[p][i] for the lane's rows 16 i + r16 of the wave's 64
             const int row_base = r * TT + wm * 64;
             float rs[4][4];
@@ -311,11 +333,18 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
             int next_bound = nkp, pcur = 0;
             for (int t = 0; t < nstage; ++t) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own 8 pieces of stage t
+                // the wave's own 8 pieces of stage t have landed (in-order return): the 16 of stages t + 1, t + 2 may still be on their way
+                if (t + 2 < nstage)
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (t + 1 < nstage)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < nstage) glds_stage(t + 1);
-                const char* sa_ = smem + (t & 1) * TSTAGE;
+                // buffer (t + 3) % 4 held stage t - 1: every wave retired its reads of it before it reached this barrier
+                if (t + 3 < nstage) glds_stage(t + 3);
+                const char* sa_ = smem + (t & (kRing - 1)) * TSTAGE;
                 const char* sb_ = sa_ + TT * TROW;
                 h8 bh[4], bl[4], ah[4], al[4];
 #pragma unroll
@@ -409,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
             }
         }
         // ---- publish: every wave's stores have left, then one lane releases and counts -- and takes the next ticket ----
+        const unsigned long long st_c = TK_NOW();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -420,7 +450,22 @@ __global__ __launch_bounds__(256, 2) void k_trsm_tickets(TkParams P) {
         __syncthreads();
         ticket = __builtin_amdgcn_readfirstlane(s_word);
         __syncthreads();
+#ifdef NNGP_TIMING_KNOBS
+        {
+            const unsigned long long st_d = TK_NOW();
+            st[type * 4 + 0] += st_b - st_a; st[type * 4 + 1] += st_c - st_b; st[type * 4 + 2] += st_d - st_c; st[type * 4 + 3] += 1;
+        }
+#else
+        (void)st_a; (void)st_b; (void)st_c;
+#endif
     }
+#ifdef NNGP_TIMING_KNOBS
+    if (tid == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_tk_stamps[i], st[i]);
+        atomicAdd(&g_tk_stamps[16], TK_NOW() - st_k0);
+        atomicAdd(&g_tk_stamps[17], 1ULL);
+    }
+#endif
 }
 
 // absolute maximum of each bs x bs block (bit pattern of a non-negative float orders like an unsigned)
@@ -482,7 +527,7 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
     // position of block column J in solve order (0 = solved first) and back
     auto pos_of = [&](int J) { return backward ? nb - 1 - J : J; };
     auto blk_at = [&](int pos) { return backward ? nb - 1 - pos : pos; };
-    const double t_split = 5.0, t_tile0 = 8.0, t_stage = 0.6;
+    const double t_split = 12.0, t_tile0 = 14.0, t_stage = 0.6;  // us: measured on the first GPU runs (publish + wait + acquire ~ 10 us an item)
     int max_pan = 4;
     if (const char* e = getenv("NNGP_TK_MAXPAN")) max_pan = std::max(1, std::min(4, atoi(e)));  // development aid
     struct Ready {
@@ -610,7 +655,7 @@ struct TrsmTickets {
     hipEvent_t ev_err = nullptr;
     bool err_pending = false;
     bool inv_ready = false;
-    int workers = 512;
+    int workers = 256;
 };
 
 static int64_t tk_items_bound(int64_t mt, int64_t nb) { return mt * (8 * nb * (nb - 1) / 2 + 24 * nb) + 64; }
@@ -659,9 +704,14 @@ int tk_create(TrsmTickets** out, int64_t np_cap, int64_t m_cap) {
         return 1;
     }
     tk->host_err[0] = tk->host_err[1] = 0;
+    if (hipMemset(tk->sync, 0, sizeof(int) * tk->sync_ints) != hipSuccess) {  // (the error word is only ever cleared here and after a report)
+        (void)hipGetLastError();
+        tk_destroy(tk);
+        return 1;
+    }
     int dev = 0, count = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && count > 0)
-        tk->workers = 2 * count;
+        tk->workers = count;
     *out = tk;
     return 0;
 }
@@ -754,6 +804,23 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     NNGP_HIP_CHECK(hipMemcpyAsync(tk->host_err, tk->sync + SY_ERROR, sizeof(int), hipMemcpyDeviceToHost, s));
     NNGP_HIP_CHECK(hipEventRecord(tk->ev_err, s));
     tk->err_pending = true;
+#ifdef NNGP_TIMING_KNOBS
+    if (getenv("NNGP_TK_STAMPS") != nullptr) {
+        unsigned long long h[20];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tk_stamps), sizeof(h)) == hipSuccess) {
+            static const char* names[4] = {"SB", "D", "SX", "U"};
+            fprintf(stderr, "tk stamps (%s, mt %d nb %d): %llu workgroups, mean kernel time per workgroup %.1f us\n", backward ? "backward" : "forward", mt, nb, h[17],
+                    h[17] ? 0.01 * (double)h[16] / (double)h[17] : 0.0);
+            for (int t = 0; t < 4; ++t)
+                fprintf(stderr, "   %-2s items %6llu: wait %.2f us  body %.2f us  publish %.2f us per item; share of workgroup time: wait %.1f %% body %.1f %% publish %.1f %%\n", names[t],
+                        h[t * 4 + 3], h[t * 4 + 3] ? 0.01 * h[t * 4] / h[t * 4 + 3] : 0.0, h[t * 4 + 3] ? 0.01 * h[t * 4 + 1] / h[t * 4 + 3] : 0.0,
+                        h[t * 4 + 3] ? 0.01 * h[t * 4 + 2] / h[t * 4 + 3] : 0.0, 100.0 * h[t * 4] / (double)h[16], 100.0 * h[t * 4 + 1] / (double)h[16], 100.0 * h[t * 4 + 2] / (double)h[16]);
+            unsigned long long z[20] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tk_stamps), z, sizeof(z));
+        }
+    }
+#endif
     if (getenv("NNGP_TK_DUMP") != nullptr && !backward) {  // development aid: what the split rows of block column 0 hold after the solve
         (void)hipDeviceSynchronize();
         std::vector<_Float16> h(8 * 2048);
