@@ -51,9 +51,9 @@ constexpr int TROW = 128;                // bytes per LDS row: 32 hi + 32 lo hal
 constexpr int TSTAGE = 2 * TT * TROW;    // A rows + B rows: 32 KB
 constexpr int64_t kLdp = 4096;           // bytes per split row (1024 k x 4 bytes), every plane buffer
 constexpr int kBs = 1024;                // block-column width
-constexpr int kQ = 8;                    // split items per (r, J): 16 rows each
+constexpr int kQ = 4;                    // split items per (r, J): 32 rows each (8 waves x 4 rows)
 
-enum { IT_SB = 0, IT_D = 1, IT_SX = 2, IT_U = 3 };
+enum { IT_SB = 0, IT_D = 1, IT_SX = 2, IT_U = 3, IT_UB = 4 };
 enum { SY_TICKET = 0, SY_ERROR = 1, SY_COUNTERS = 16 };
 
 struct TkParams {
@@ -98,26 +98,38 @@ __device__ __forceinline__ void st4_wt(float* p, float v) {
 
 #ifdef NNGP_TIMING_KNOBS
 // timing study (knobs build): s_memrealtime ticks (10 ns) summed over all workgroups, per item type t = 0..3:
-// [t*4 + 0] wait + acquire, [t*4 + 1] body, [t*4 + 2] publish + next ticket, [t*4 + 3] items; [16] kernel ticks summed, [17] workgroups
-__device__ unsigned long long g_tk_stamps[20];
+// [t*4 + 0] wait + acquire, [t*4 + 1] body, [t*4 + 2] publish + next ticket, [t*4 + 3] items (t = 0..4); [20] kernel ticks summed, [21] workgroups
+__device__ unsigned long long g_tk_stamps[24];
 #define TK_NOW() __builtin_amdgcn_s_memrealtime()
 #else
 #define TK_NOW() 0ULL
 #endif
 
-constexpr int kRing = 4;  // operand stages in LDS: three in flight while one is multiplied
+constexpr int kRing = 4;                 // 128-tile items: operand stages in LDS, three in flight while one is multiplied
+constexpr int HT2 = 256;                 // bulk update tile edge
+constexpr int HSTAGE2 = 2 * HT2 * TROW;  // its stage: A rows + B rows, 64 KB
 
-__global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
-    __shared__ __attribute__((aligned(1024))) char smem[kRing * TSTAGE];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
-    int& s_word = *reinterpret_cast<int*>(smem);                     // ticket / wait status: only touched between items
+// 512 threads = 8 waves, one workgroup per compute unit (all 160 KB of LDS).  Bulk updates are 256 x 256 tiles on all eight waves --
+// the main loop of k_gemm_nt_h3v2 (gemm_h3.hip: 2 x 4 waves, wave sub-tile 128 x 64, two 64 KB stages, two staggered wave groups):
+// with 128 x 128 tiles everywhere the solve moved 33 GB of operands per solve through the fabric and ran at ITS rate (5.6 ms at
+// N = 32768, M = 1024, the matrix pipe 40 % busy; DESIGN_NOTES R5-T) -- a 256 x 256 tile needs half the bytes per flop.  The items on
+// the dependency chain (diagonal products, the last update of a block column before it is solved) stay 128 x 128 tiles on waves 0-3
+// with a four-stage ring: they are latency, not bandwidth.
+__global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
+    __shared__ __attribute__((aligned(1024))) char smem[160 * 1024];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
+    int& s_word = *reinterpret_cast<int*>(smem);                      // ticket / wait status: only touched between items
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = __builtin_amdgcn_readfirstlane(wave >> 1);
-    const int wn = __builtin_amdgcn_readfirstlane(wave & 1);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = __builtin_amdgcn_readfirstlane((wave >> 1) & 1);  // 128-tile items (waves 0-3 as 2 x 2)
+    const int wn = __builtin_amdgcn_readfirstlane(wave & 1);
+    const int group = __builtin_amdgcn_readfirstlane(wave >> 2);     // 256-tile items (2 x 4)
+    const int w4 = __builtin_amdgcn_readfirstlane(wave & 3);
     const int l3 = lane >> 3;
     const int r16 = lane & 15, q4 = lane >> 4;
-    const unsigned lane_off = (unsigned)l3 * (unsigned)kLdp + (((lane & 7) ^ ((4 * (wv & 1) + (l3 >> 1)) & 7)) << 4);
+    // an 8-row piece of split rows lands as 1 KB of LDS; the 16-byte chunk index is XOR-swizzled by (row >> 1) & 7, a lane constant
+    // because every wave only moves pieces of one parity (128-tile items: piece = 4 e + wave; 256-tile items: 16 group + 4 e + w4)
+    const unsigned lane_off = (unsigned)l3 * (unsigned)kLdp + (((lane & 7) ^ ((4 * (w4 & 1) + (l3 >> 1)) & 7)) << 4);
     const unsigned frag_hi = (unsigned)r16 * TROW + (((unsigned)q4 ^ ((unsigned)r16 >> 1)) << 4);
     const unsigned frag_lo = frag_hi ^ 64u;
     int* const sync = P.sync;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
 
     // The loop holds exactly ONE block that only thread 0 executes (publish + next ticket, at its bottom, between two workgroup
     // barriers).  With the ticket fetch in a block of its own at the top, hipcc threaded thread 0's path from the publish block
-    // across the back edge into the fetch block, which made the rest of the loop an INNER loop that the other 255 threads never leave:
+    // across the back edge into the fetch block, which made the rest of the loop an INNER loop that the other threads never leave:
     // lane 0 of wave 0 waited for its wave's reconvergence, nothing was ever published (first GPU run of this kernel: every workgroup
     // holding its first ticket, no counter moving).
     if (tid == 0) s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
     int ticket = __builtin_amdgcn_readfirstlane(s_word);
     __syncthreads();
 #ifdef NNGP_TIMING_KNOBS
-    unsigned long long st[16] = {};
+    unsigned long long st[20] = {};
     const unsigned long long st_k0 = TK_NOW();
 #endif
     while (ticket < P.n_items) {
@@ -146,20 +158,25 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
         const int type = __builtin_amdgcn_readfirstlane(it.x & 15), npan = __builtin_amdgcn_readfirstlane((it.x >> 4) & 15);
         const int r = __builtin_amdgcn_readfirstlane(it.y), cq = __builtin_amdgcn_readfirstlane(it.z),
                   J = __builtin_amdgcn_readfirstlane(it.w);
-        // block column of a tile, its tile count, panels applied to it when it is complete
-        const int Jc = (type == IT_U || type == IT_D) ? cq / 8 : J;
+        // r, cq: tile of 128 rows / columns (IT_UB: tile of 256 = tiles 2 r, 2 r + 1 / 2 cq, 2 cq + 1; split items: cq = row group)
+        const int Jc = type == IT_UB ? cq / 4 : (type == IT_U || type == IT_D) ? cq / 8 : J;  // block column of the target
         const int ct_j = (Jc == nb - 1) ? P.tail_ct : 8;
 
         // ---- dependencies: wave 0 polls, one counter per lane ----
-        if (wave == 0) {
+        if (wv == 0) {
             const int* addr = sync + SY_ERROR;
             int need = 0;
             bool active = false;
+            // an update: the latest block column of the item is split (for its rows); its tiles have received everything before the
+            // item's earliest block column
+            const int first_in_time = P.backward ? J + npan - 1 : J - npan + 1;
+            const int need_up = P.backward ? nb - 1 - first_in_time : first_in_time;
             if (type == IT_U) {
-                // the latest block column of the item is split; the tile has received everything before the item's earliest one
-                const int first_in_time = P.backward ? J + npan - 1 : J - npan + 1;
                 if (lane == 0) { addr = cnt_xs + r * nb + J; need = kQ; active = true; }
-                if (lane == 1) { addr = cnt_up + r * P.ctiles + cq; need = P.backward ? nb - 1 - first_in_time : first_in_time; active = true; }
+                if (lane == 1) { addr = cnt_up + r * P.ctiles + cq; need = need_up; active = true; }
+            } else if (type == IT_UB) {
+                if (lane < 2) { addr = cnt_xs + (2 * r + lane) * nb + J; need = kQ; active = true; }
+                else if (lane < 6) { addr = cnt_up + (2 * r + ((lane - 2) >> 1)) * P.ctiles + 2 * cq + ((lane - 2) & 1); need = need_up; active = true; }
             } else if (type == IT_D) {
                 if (lane == 0) { addr = cnt_bs + r * nb + Jc; need = kQ; active = true; }
             } else if (type == IT_SX) {
@@ -188,18 +205,18 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
         __syncthreads();
         const int status = __builtin_amdgcn_readfirstlane(s_word);
         __syncthreads();
-        if (status != 0) break;
+        if (status != 0) break;  // (uniform)
         const unsigned long long st_b = TK_NOW();
 
         int* done_counter;
-        int done_add = 1;
+        int done_add = 1, done_n = 1, done_stride2 = 0;  // counters done_counter[0 .. done_n), UB: also the next row tile's (stride2)
         if (type == IT_SB || type == IT_SX) {
-            // ---- split item: rows r*128 + cq*16 + wave*4 + i, columns of block J ----
+            // ---- split item: rows r*128 + cq*32 + wave*4 + i, columns of block J ----
             const bool is_x = type == IT_SX;
             char* planes = (is_x ? P.planes_x : P.planes_d) + (int64_t)J * P.p_stride;
             float* rinv = (is_x ? P.rinv_x : P.rinv_d) + (int64_t)J * P.r_stride;
             const int width = ct_j * TT;
-            const int row0 = r * TT + cq * 16 + wv * 4;
+            const int row0 = r * TT + cq * 32 + wv * 4;
             f32x4v v[4][2][2];
             float mx[4];
 #pragma unroll
@@ -253,8 +270,185 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
                 }
             }
             done_counter = (is_x ? cnt_xs : cnt_bs) + r * nb + J;
+        } else if (type == IT_UB) {
+            // ---- bulk update: B[256 r .., 256 cq ..] -= sum over npan block columns X_J[rows] L[cols, J]^T ----
+            const int ct_p = (J == nb - 1) ? P.tail_ct : 8;  // (a tail-width block column is never grouped with others)
+            const int kb_hi = ct_p * 4 - 1;
+            const char* pa = P.planes_x + (int64_t)J * P.p_stride + (int64_t)(r * HT2) * kLdp;
+            const char* pb = P.lplanes + (int64_t)J * P.l_stride + (int64_t)(cq * HT2) * kLdp;
+            const int64_t a_pst = P.backward ? P.p_stride : -P.p_stride;
+            const int64_t b_pst = P.backward ? P.l_stride : -P.l_stride;
+            const int nkp = kb_hi + 1;
+            const int nstage = nkp * npan;
+            int cur_p = 0, cur_kb = kb_hi;
+            int64_t offa = 0, offb = 0;
+            auto cursor_take = [&]() {  // offsets of the cursor's k-block; advances the cursor
+                offa = (int64_t)cur_kb * 128 + (int64_t)cur_p * a_pst;
+                offb = (int64_t)cur_kb * 128 + (int64_t)cur_p * b_pst;
+                if (--cur_kb < 0) { cur_kb = kb_hi; ++cur_p; }
+            };
+            auto glds_b = [&](int t) {  // the wave's 4 B pieces of stage t
+                char* dst = smem + (t & 1) * HSTAGE2 + HT2 * TROW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int piece = group * 16 + e * 4 + w4;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(pb + offb + (int64_t)piece * 8 * kLdp + lane_off), (lds_void*)(dst + piece * 1024), 16, 0, 0);
+                }
+            };
+            auto glds_a = [&](int t) {  // the wave's 4 A pieces of stage t: rows 0-63 of its group first (e = 0, 1), then rows 64-127
+                char* dst = smem + (t & 1) * HSTAGE2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int piece = group * 16 + e * 4 + w4;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(pa + offa + (int64_t)piece * 8 * kLdp + lane_off), (lds_void*)(dst + piece * 1024), 16, 0, 0);
+                }
+            };
+            cursor_take();
+            glds_b(0);
+            glds_a(0);
+            // acc[i][j][e] = tile(group*128 + 16 i + r16, w4*64 + 16 j + 4 q4 + e): the lane's rows 16 i + r16 of its group's 128
+            const int row_base = r * HT2 + group * 128;
+            float rs_cur[8];
+            {
+                const float* rv = P.rinv_x + (int64_t)J * P.r_stride + row_base + r16;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rs_cur[i] = rv[16 * i];
+            }
+            f32x4v acc[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (group == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind group 0
+            int next_bound = nkp, pcur = 0;
+            for (int t = 0; t < nstage; ++t) {
+                const char* sa_ = smem + (t & 1) * HSTAGE2;
+                const char* sb_ = sa_ + HT2 * TROW;
+                const bool more = t + 1 < nstage;
+                if (t == next_bound) {
+                    // block-column boundary: the sums so far carry the row scales of block column pcur, the terms to come those of the
+                    // next one (ratios of powers of two: exact).  The scale loads wait for everything in flight: once per 32 stages.
+                    next_bound += nkp;
+                    ++pcur;
+                    const float* rv = P.rinv_x + (int64_t)(P.backward ? J + pcur : J - pcur) * P.r_stride + row_base + r16;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float nxt = rv[16 * i];
+                        const float f = rs_cur[i] / nxt;
+                        rs_cur[i] = nxt;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][e] *= f;
+                    }
+                }
+                if (more) cursor_take();
+                h8 bh[4], bl[4], ah[4], al[4];
+                // ---- phase A: wave rows 0-63 ----
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rb = (w4 * 64 + j * 16) * TROW;
+                    bh[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_hi);
+                    bl[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_lo);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rb = (group * 128 + i * 16) * TROW;
+                    ah[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_hi);
+                    al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
+                }
+                if (more) {
+                    glds_b(t + 1);
+                    if (t > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires the wave's last two A pieces of stage t (read in phase B)
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- phase B: wave rows 64-127 ----
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rb = (group * 128 + 64 + i * 16) * TROW;
+                    ah[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_hi);
+                    al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
+                }
+                if (more) {
+                    glds_a(t + 1);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires the B pieces issued in phase A
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[4 + i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[4 + i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[4 + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // retires the A pieces of rows 0-63 of stage t+1
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (group == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
+            // ---- epilogue: two 16-row bands at a time ----
+            const unsigned voff = ((unsigned)r16 * (unsigned)P.ldb + 4u * (unsigned)q4) * 4u;
+            char* cw = reinterpret_cast<char*>(P.b + (int64_t)row_base * P.ldb + (int64_t)cq * HT2 + w4 * 64);
+            const int64_t band = (int64_t)16 * P.ldb * 4;
+#pragma unroll
+            for (int ib = 0; ib < 8; ib += 2) {
+                f32x4v cold[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cold[i][j] = *reinterpret_cast<const f32x4v*>(cw + (ib + i) * band + voff + 64 * j);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float fs = -rs_cur[ib + i] * P.l_iscale;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[ib + i][j][e] = fmaf(fs, acc[ib + i][j][e], cold[i][j][e]);
+                        st16_wt(cw + (ib + i) * band + voff + 64 * j, acc[ib + i][j]);
+                    }
+                }
+            }
+            done_counter = cnt_up + (2 * r) * P.ctiles + 2 * cq;
+            done_add = npan;
+            done_n = 2;
+            done_stride2 = P.ctiles;
         } else {
-            // ---- tile item ----
+            // ---- 128 x 128 tile item (diagonal product, or an update on the chain) on waves 0-3; waves 4-7 keep the barriers ----
             const bool is_u = type == IT_U;
             const int cl = cq - Jc * 8;  // tile inside its block column
             // operands: k-blocks kb_hi down to kb_lo of every panel; panel p lies a_pst / b_pst bytes from panel p - 1
@@ -279,162 +473,165 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
             }
             const int nkp = kb_hi - kb_lo + 1;
             const int nstage = nkp * (is_u ? npan : 1);
-            int cur_p = 0, cur_kb = kb_hi;
-            auto glds_stage = [&](int t) {  // the wave's 4 B pieces and 4 A pieces of stage t at the cursor; advances the cursor
-                const int64_t offa = (int64_t)cur_kb * 128 + (int64_t)cur_p * a_pst;
-                const int64_t offb = (int64_t)cur_kb * 128 + (int64_t)cur_p * b_pst;
-                if (--cur_kb < kb_lo) { cur_kb = kb_hi; ++cur_p; }
-                char* dst = smem + (t & (kRing - 1)) * TSTAGE;
+            if (wv >= 4) {
+                for (int t = 0; t < nstage; ++t) __builtin_amdgcn_s_barrier();
+                done_counter = is_u ? cnt_up + r * P.ctiles + cq : cnt_xd + r * nb + Jc;
+                done_add = is_u ? npan : 1;
+            } else {
+                int cur_p = 0, cur_kb = kb_hi;
+                auto glds_stage = [&](int t) {  // the wave's 4 B pieces and 4 A pieces of stage t at the cursor; advances the cursor
+                    const int64_t offa = (int64_t)cur_kb * 128 + (int64_t)cur_p * a_pst;
+                    const int64_t offb = (int64_t)cur_kb * 128 + (int64_t)cur_p * b_pst;
+                    if (--cur_kb < kb_lo) { cur_kb = kb_hi; ++cur_p; }
+                    char* dst = smem + (t & (kRing - 1)) * TSTAGE;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int piece = e * 4 + wv;
-                    __builtin_amdgcn_global_load_lds((glb_void*)(pb + offb + (int64_t)piece * 8 * kLdp + lane_off),
-                                                     (lds_void*)(dst + TT * TROW + piece * 1024), 16, 0, 0);
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        const int piece = e * 4 + wv;
+                        __builtin_amdgcn_global_load_lds((glb_void*)(pb + offb + (int64_t)piece * 8 * kLdp + lane_off),
+                                                         (lds_void*)(dst + TT * TROW + piece * 1024), 16, 0, 0);
+                    }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int piece = e * 4 + wv;
-                    __builtin_amdgcn_global_load_lds((glb_void*)(pa + offa + (int64_t)piece * 8 * kLdp + lane_off),
-                                                     (lds_void*)(dst + piece * 1024), 16, 0, 0);
-                }
-            };
-            // The operands arrive HBM / L2-latency bound (~1.7 us a stage under load, against 0.4 us of MFMAs): stages t + 1 .. t + 3 are in
-            // flight while stage t is multiplied (the first form of this kernel, two workgroups per compute unit with two stages each, spent
-            // 2 us per stage: DESIGN_NOTES R5-T)
-            glds_stage(0);
-            if (nstage > 1) glds_stage(1);
-            if (nstage > 2) glds_stage(2);
-            // per-row scales of the A operand's panels (powers of two): rs[p][i] for the lane's rows 16 i + r16 of the wave's 64
-            const int row_base = r * TT + wm * 64;
-            float rs[4][4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rs[p][i] = 1.0f;
-            if (is_u) {
+                    for (int e = 0; e < 4; ++e) {
+                        const int piece = e * 4 + wv;
+                        __builtin_amdgcn_global_load_lds((glb_void*)(pa + offa + (int64_t)piece * 8 * kLdp + lane_off),
+                                                         (lds_void*)(dst + piece * 1024), 16, 0, 0);
+                    }
+                };
+                // The operands arrive latency bound (~1.7 us a stage under load, against 0.4 us of MFMAs): stages t + 1 .. t + 3 are in
+                // flight while stage t is multiplied
+                glds_stage(0);
+                if (nstage > 1) glds_stage(1);
+                if (nstage > 2) glds_stage(2);
+                // per-row scales of the A operand's panels (powers of two): rs[p][i] for the lane's rows 16 i + r16 of the wave's 64
+                const int row_base = r * TT + wm * 64;
+                float rs[4][4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    if (p < npan) {
-                        const float* rv = P.rinv_x + (int64_t)(P.backward ? J + p : J - p) * P.r_stride + row_base + r16;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) rs[p][i] = rv[16 * i];
+                    for (int i = 0; i < 4; ++i) rs[p][i] = 1.0f;
+                if (is_u) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (p < npan) {
+                            const float* rv = P.rinv_x + (int64_t)(P.backward ? J + p : J - p) * P.r_stride + row_base + r16;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rs[p][i] = rv[16 * i];
+                        }
+                } else {
+                    const float* rv = P.rinv_d + (int64_t)Jc * P.r_stride + row_base + r16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rs[0][i] = rv[16 * i];
+                }
+                f32x4v acc[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+                int next_bound = nkp, pcur = 0;
+                for (int t = 0; t < nstage; ++t) {
+                    // the wave's own 8 pieces of stage t have landed (in-order return): the 16 of stages t + 1, t + 2 may still be on their way
+                    if (t + 2 < nstage)
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    else if (t + 1 < nstage)
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // buffer (t + 3) % 4 held stage t - 1: every wave retired its reads of it before it reached this barrier
+                    if (t + 3 < nstage) glds_stage(t + 3);
+                    const char* sa_ = smem + (t & (kRing - 1)) * TSTAGE;
+                    const char* sb_ = sa_ + TT * TROW;
+                    h8 bh[4], bl[4], ah[4], al[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rb = (wn * 64 + j * 16) * TROW;
+                        bh[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_hi);
+                        bl[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_lo);
                     }
-            } else {
-                const float* rv = P.rinv_d + (int64_t)Jc * P.r_stride + row_base + r16;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rs[0][i] = rv[16 * i];
-            }
-            // (the compiler waits for these loads where they are first used: behind the first stage's wait anyway)
-
-            f32x4v acc[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-            int next_bound = nkp, pcur = 0;
-            for (int t = 0; t < nstage; ++t) {
-                // the wave's own 8 pieces of stage t have landed (in-order return): the 16 of stages t + 1, t + 2 may still be on their way
-                if (t + 2 < nstage)
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if (t + 1 < nstage)
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // buffer (t + 3) % 4 held stage t - 1: every wave retired its reads of it before it reached this barrier
-                if (t + 3 < nstage) glds_stage(t + 3);
-                const char* sa_ = smem + (t & (kRing - 1)) * TSTAGE;
-                const char* sb_ = sa_ + TT * TROW;
-                h8 bh[4], bl[4], ah[4], al[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rb = (wn * 64 + j * 16) * TROW;
-                    bh[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_hi);
-                    bl[j] = *reinterpret_cast<const h8*>(sb_ + rb + frag_lo);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rb = (wm * 64 + i * 16) * TROW;
-                    ah[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_hi);
-                    al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
-                }
-                if (t == next_bound) {
-                    // panel boundary: the sums so far carry panel pcur's row scales, the terms to come panel pcur + 1's
-                    // (ratios of powers of two: exact)
-                    next_bound += nkp;
-                    float f[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float a = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : rs[2][i];
-                        const float b = pcur == 0 ? rs[1][i] : pcur == 1 ? rs[2][i] : rs[3][i];
-                        f[i] = a / b;
+                        const int rb = (wm * 64 + i * 16) * TROW;
+                        ah[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_hi);
+                        al[i] = *reinterpret_cast<const h8*>(sa_ + rb + frag_lo);
                     }
-                    ++pcur;
+                    if (t == next_bound) {
+                        // panel boundary: the sums so far carry panel pcur's row scales, the terms to come panel pcur + 1's
+                        // (ratios of powers of two: exact)
+                        next_bound += nkp;
+                        float f[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float a = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : rs[2][i];
+                            const float b = pcur == 0 ? rs[1][i] : pcur == 1 ? rs[2][i] : rs[3][i];
+                            f[i] = a / b;
+                        }
+                        ++pcur;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i][j][e] *= f[i];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- epilogue: acc[i][j][e] = tile(wm*64 + 16 i + r16, wn*64 + 16 j + 4 q4 + e) ----
+                float fs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float last = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : pcur == 2 ? rs[2][i] : rs[3][i];
+                    fs[i] = last * (is_u ? -P.l_iscale : P.dinv_iscale[Jc]);
+                }
+                const unsigned voff = ((unsigned)r16 * (unsigned)P.ldb + 4u * (unsigned)q4) * 4u;
+                char* cw = reinterpret_cast<char*>(P.b + (int64_t)(row_base)*P.ldb + (int64_t)cq * TT + wn * 64);
+                const int64_t band = (int64_t)16 * P.ldb * 4;
+                if (is_u) {
+                    f32x4v cold[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cold[i][j] = *reinterpret_cast<const f32x4v*>(cw + i * band + voff + 64 * j);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[i][j][e] *= f[i];
+                            for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(fs[i], acc[i][j][e], cold[i][j][e]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][e] *= fs[i];
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- epilogue: acc[i][j][e] = tile(wm*64 + 16 i + r16, wn*64 + 16 j + 4 q4 + e) ----
-            float fs[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float last = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : pcur == 2 ? rs[2][i] : rs[3][i];
-                fs[i] = last * (is_u ? -P.l_iscale : P.dinv_iscale[Jc]);
-            }
-            const unsigned voff = ((unsigned)r16 * (unsigned)P.ldb + 4u * (unsigned)q4) * 4u;
-            char* cw = reinterpret_cast<char*>(P.b + (int64_t)(row_base)*P.ldb + (int64_t)cq * TT + wn * 64);
-            const int64_t band = (int64_t)16 * P.ldb * 4;
-            if (is_u) {
-                f32x4v cold[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cold[i][j] = *reinterpret_cast<const f32x4v*>(cw + i * band + voff + 64 * j);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(fs[i], acc[i][j][e], cold[i][j][e]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][e] *= fs[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) st16_wt(cw + i * band + voff + 64 * j, acc[i][j]);
-            if (is_u) {
-                done_counter = cnt_up + r * P.ctiles + cq;
-                done_add = npan;
-            } else {
-                done_counter = cnt_xd + r * nb + Jc;
+                    for (int j = 0; j < 4; ++j) st16_wt(cw + i * band + voff + 64 * j, acc[i][j]);
+                if (is_u) {
+                    done_counter = cnt_up + r * P.ctiles + cq;
+                    done_add = npan;
+                } else {
+                    done_counter = cnt_xd + r * nb + Jc;
+                }
             }
         }
         // ---- publish: every wave's stores have left, then one lane releases and counts -- and takes the next ticket ----
@@ -444,7 +641,10 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicAdd(done_counter, done_add);
+            for (int a = 0; a < done_n; ++a) {
+                atomicAdd(done_counter + a, done_add);
+                if (done_stride2 != 0) atomicAdd(done_counter + done_stride2 + a, done_add);
+            }
             s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
         }
         __syncthreads();
@@ -461,9 +661,9 @@ __global__ __launch_bounds__(256, 1) void k_trsm_tickets(TkParams P) {
     }
 #ifdef NNGP_TIMING_KNOBS
     if (tid == 0) {
-        for (int i = 0; i < 16; ++i) atomicAdd(&g_tk_stamps[i], st[i]);
-        atomicAdd(&g_tk_stamps[16], TK_NOW() - st_k0);
-        atomicAdd(&g_tk_stamps[17], 1ULL);
+        for (int i = 0; i < 20; ++i) atomicAdd(&g_tk_stamps[i], st[i]);
+        atomicAdd(&g_tk_stamps[20], TK_NOW() - st_k0);
+        atomicAdd(&g_tk_stamps[21], 1ULL);
     }
 #endif
 }
@@ -515,27 +715,28 @@ __global__ __launch_bounds__(256) void k_split_blocks(const float* __restrict__ 
 // List scheduling on `workers` simulated workgroups with rough item durations: an item enters the table when the simulation starts
 // it, i.e. after everything it depends on has FINISHED there -- so every dependency has a lower ticket whatever the real timing is.
 // Priority: earliest deadline first, the deadline of an item being the block column it feeds (diagonal chain items before the
-// updates of the next block column).  A tile that comes up for an update takes every finished block column that is waiting for
-// it, up to four (K = 4096 in one pass over the tile): deep K where the chip is throughput-bound, single panels near the chain.
-struct SimItem {
-    int type, r, cq, J, npan;
-};
-
+// updates of the next block column).  Updates come in two shapes: a 2 x 2 group of tiles takes every finished block column that is
+// waiting for it EXCEPT the one right before its own block, up to four at a time, as one 256 x 256 item (deep K where the chip is
+// throughput-bound); the last block column before a tile's own -- the update on the dependency chain -- is applied tile by tile
+// (128 x 128 items: four times the parallelism where only latency counts).  Tiles without a partner (odd row-tile count, odd tail)
+// take all their updates as 128 x 128 items.
 void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std::vector<int4>& out) {
     const int ctiles = (nb - 1) * 8 + tail_ct;
     auto ct_of = [&](int J) { return J == nb - 1 ? tail_ct : 8; };
-    // position of block column J in solve order (0 = solved first) and back
-    auto pos_of = [&](int J) { return backward ? nb - 1 - J : J; };
+    auto pos_of = [&](int J) { return backward ? nb - 1 - J : J; };  // position of block column J in solve order (0 = solved first)
     auto blk_at = [&](int pos) { return backward ? nb - 1 - pos : pos; };
-    const double t_split = 12.0, t_tile0 = 14.0, t_stage = 0.6;  // us: measured on the first GPU runs (publish + wait + acquire ~ 10 us an item)
+    const double t_split = 10.0, t_tile0 = 14.0, t_stage = 0.6, t_big0 = 24.0, t_bigstage = 1.6;  // us, from the stamps of GPU runs
     int max_pan = 4;
     if (const char* e = getenv("NNGP_TK_MAXPAN")) max_pan = std::max(1, std::min(4, atoi(e)));  // development aid
+    const bool no_big = getenv("NNGP_TK_NOBIG") != nullptr;                                      // development aid: 128 x 128 items only
+    enum { K_TILE = 0, K_PAIR = 1 };
     struct Ready {
-        int key, c, r, type, J;  // J: block (S, D) ; for U: unused
+        int key, c, r, type, J, kind;  // type IT_*; kind: what an update entry stands for
         bool operator<(const Ready& o) const {  // priority_queue: largest first -> invert
             if (key != o.key) return key > o.key;
             if (c != o.c) return c > o.c;
-            return r > o.r;
+            if (r != o.r) return r > o.r;
+            return type > o.type;
         }
     };
     struct Done {
@@ -545,55 +746,93 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
     };
     std::priority_queue<Ready> ready;
     std::priority_queue<Done> running;
-    std::vector<int> up((size_t)mt * ctiles, 0);      // panels applied (in solve order positions)
-    std::vector<char> busy((size_t)mt * ctiles, 0);   // an update of the tile is running or queued
+    std::vector<int> up((size_t)mt * ctiles, 0);      // block columns applied to a tile (positions in solve order)
+    std::vector<char> busy((size_t)mt * ctiles, 0);   // an update of the tile is queued or running
     std::vector<int> xs((size_t)mt * nb, 0), xd((size_t)mt * nb, 0), bs((size_t)mt * nb, 0), tiles_final((size_t)mt * nb, 0);
     std::vector<int> xready((size_t)mt, 0);           // positions [0, xready[r]) have their split X
-    // a tile (r, c) in block position pc needs panels at positions 0 .. pc - 1, in order
-    auto queue_tile = [&](int r, int c) {
-        const size_t id = (size_t)r * ctiles + c;
+    const int mt2 = mt / 2, ct2 = ctiles / 2;         // 2 x 2 groups: row tiles (2 r2, 2 r2 + 1), column tiles (2 c2, 2 c2 + 1) -- same block (8 | 2 c2)
+    auto paired = [&](int r, int c) { return !no_big && r < 2 * mt2 && c < 2 * ct2 && (c / 8 != nb - 1 || (c % 8) + (c % 2 == 0 ? 1 : 0) < ct_of(nb - 1)); };
+    auto tile_id = [&](int r, int c) { return (size_t)r * ctiles + c; };
+    // the chain update of a tile: only its last block column is missing and that one is split
+    auto queue_final = [&](int r, int c) {
+        const size_t id = tile_id(r, c);
+        const int pc = pos_of(c / 8);
+        if (busy[id] || pc == 0 || up[id] != pc - 1 || xready[r] < pc) return;
+        busy[id] = 1;
+        ready.push(Ready{2 * pc - 1, c, r, IT_U, 0, K_TILE});
+    };
+    // an unpaired tile takes everything as 128 x 128 items
+    auto queue_single = [&](int r, int c) {
+        const size_t id = tile_id(r, c);
         const int pc = pos_of(c / 8);
         if (busy[id] || up[id] >= pc || up[id] >= xready[r]) return;
         busy[id] = 1;
-        ready.push(Ready{2 * pc - 1, c, r, IT_U, 0});
+        ready.push(Ready{2 * pc - 1, c, r, IT_U, 0, K_TILE});
+    };
+    auto queue_pair = [&](int r2, int c2) {
+        const int r = 2 * r2, c = 2 * c2;
+        const int pc = pos_of(c / 8);
+        const size_t id = tile_id(r, c);
+        const int p0 = up[id];
+        for (int dr = 0; dr < 2; ++dr)
+            for (int dc = 0; dc < 2; ++dc)
+                if (busy[tile_id(r + dr, c + dc)] || up[tile_id(r + dr, c + dc)] != p0) return;
+        const int xr = std::min(xready[r], xready[r + 1]);
+        if (std::min(pc - 1, xr) - p0 < 1) return;
+        for (int dr = 0; dr < 2; ++dr)
+            for (int dc = 0; dc < 2; ++dc) busy[tile_id(r + dr, c + dc)] = 1;
+        ready.push(Ready{2 * pc - 1, c, r, IT_UB, 0, K_PAIR});
+    };
+    auto requeue_tile = [&](int r, int c) {
+        if (paired(r, c)) {
+            queue_pair(r / 2, c / 2);
+            queue_final(r, c);
+        } else {
+            queue_single(r, c);
+        }
     };
     auto push_block_items = [&](int type, int r, int J) {
         const int n = type == IT_D ? ct_of(J) : kQ;
-        for (int i = 0; i < n; ++i) ready.push(Ready{2 * pos_of(J), type == IT_D ? J * 8 + i : i, r, type, J});
+        for (int i = 0; i < n; ++i) ready.push(Ready{2 * pos_of(J), type == IT_D ? J * 8 + i : i, r, type, J, K_TILE});
     };
     for (int r = 0; r < mt; ++r) push_block_items(IT_SB, r, blk_at(0));
     int free_workers = workers;
     double now = 0.0;
-    size_t total = 0;
-    for (int J = 0; J < nb; ++J) total += (size_t)mt * (2 * kQ + ct_of(J));
     out.clear();
     for (;;) {
         while (free_workers > 0 && !ready.empty()) {
             const Ready it = ready.top();
             ready.pop();
             int4 rec;
-            double dur;
             Done d{};
-            if (it.type == IT_U) {
-                const size_t id = (size_t)it.r * ctiles + it.c;
+            if (it.type == IT_UB) {
+                const int r = it.r, c = it.c, pc = pos_of(c / 8);
+                const int p0 = up[tile_id(r, c)];
+                int avail = std::min(pc - 1, std::min(xready[r], xready[r + 1])) - p0;
+                if (avail > max_pan) avail = max_pan;
+                if (backward && tail_ct != 8 && p0 == 0) avail = 1;  // a tail-width block column goes alone
+                const int plast = p0 + avail - 1;                    // latest block column of the item in solve order = first processed
+                rec = int4{IT_UB | (avail << 4), r / 2, c / 2, blk_at(plast)};
+                const int nk = (backward && tail_ct != 8 && p0 == 0) ? tail_ct * 4 : 32;
+                d = Done{now + t_big0 + t_bigstage * nk * avail, IT_UB, r, c, 0, avail};
+            } else if (it.type == IT_U) {
+                const size_t id = tile_id(it.r, it.c);
                 const int pc = pos_of(it.c / 8);
                 const int p0 = up[id];
                 int avail = std::min(pc, xready[it.r]) - p0;
                 if (avail > max_pan) avail = max_pan;
-                // a tail-width panel (the last block column: first in the backward order) goes alone
                 if (backward && tail_ct != 8 && p0 == 0) avail = 1;
-                const int plast = p0 + avail - 1;  // latest panel of the item in solve order = first processed
+                const int plast = p0 + avail - 1;
                 rec = int4{IT_U | (avail << 4), it.r, it.c, blk_at(plast)};
-                dur = t_tile0 + t_stage * 32 * avail;
-                d = Done{now + dur, IT_U, it.r, it.c, 0, avail};
+                const int nk = (backward && tail_ct != 8 && p0 == 0) ? tail_ct * 4 : 32;
+                d = Done{now + t_tile0 + t_stage * nk * avail, IT_U, it.r, it.c, 0, avail};
             } else {
                 rec = int4{it.type | (1 << 4), it.r, it.c, it.J};
+                double dur = t_split;
                 if (it.type == IT_D) {
                     const int cl = it.c - it.J * 8;
                     const int nk = backward ? (ct_of(it.J) - cl) * 4 : (cl + 1) * 4;
                     dur = t_tile0 + t_stage * nk;
-                } else {
-                    dur = t_split;
                 }
                 d = Done{now + dur, it.type, it.r, it.c, it.J, 1};
             }
@@ -615,21 +854,27 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
             if (++xs[(size_t)r * nb + d.J] == kQ) {
                 xready[r] = pos_of(d.J) + 1;
                 for (int c = 0; c < ctiles; ++c)
-                    if (pos_of(c / 8) > pos_of(d.J)) queue_tile(r, c);
+                    if (pos_of(c / 8) > pos_of(d.J)) requeue_tile(r, c);
             }
         } else {
-            const size_t id = (size_t)r * ctiles + d.cq;
-            up[id] += d.npan;
-            busy[id] = 0;
-            const int Jt = d.cq / 8;
-            if (up[id] == pos_of(Jt)) {
-                if (++tiles_final[(size_t)r * nb + Jt] == ct_of(Jt)) push_block_items(IT_SB, r, Jt);
-            } else {
-                queue_tile(r, d.cq);
-            }
+            const int nr = d.type == IT_UB ? 2 : 1;
+            for (int dr = 0; dr < nr; ++dr)
+                for (int dc = 0; dc < nr; ++dc) {
+                    const size_t id = tile_id(r + dr, d.cq + dc);
+                    up[id] += d.npan;
+                    busy[id] = 0;
+                }
+            for (int dr = 0; dr < nr; ++dr)
+                for (int dc = 0; dc < nr; ++dc) {
+                    const int rr = r + dr, cc = d.cq + dc, Jt = cc / 8;
+                    if (up[tile_id(rr, cc)] == pos_of(Jt)) {
+                        if (++tiles_final[(size_t)rr * nb + Jt] == ct_of(Jt)) push_block_items(IT_SB, rr, Jt);
+                    } else {
+                        requeue_tile(rr, cc);
+                    }
+                }
         }
     }
-    (void)total;
 }
 
 }  // namespace
@@ -799,24 +1044,24 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     NNGP_HIP_CHECK(hipMemsetAsync(tk->sync + SY_ERROR + 1, 0, sizeof(int) * (used - SY_ERROR - 1), s));
     int grid = tk->workers;
     if (grid > P.n_items) grid = P.n_items;
-    hipLaunchKernelGGL(k_trsm_tickets, dim3((unsigned)grid), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_trsm_tickets, dim3((unsigned)grid), dim3(512), 0, s, P);
     NNGP_HIP_CHECK(hipGetLastError());
     NNGP_HIP_CHECK(hipMemcpyAsync(tk->host_err, tk->sync + SY_ERROR, sizeof(int), hipMemcpyDeviceToHost, s));
     NNGP_HIP_CHECK(hipEventRecord(tk->ev_err, s));
     tk->err_pending = true;
 #ifdef NNGP_TIMING_KNOBS
     if (getenv("NNGP_TK_STAMPS") != nullptr) {
-        unsigned long long h[20];
+        unsigned long long h[24];
         (void)hipDeviceSynchronize();
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tk_stamps), sizeof(h)) == hipSuccess) {
-            static const char* names[4] = {"SB", "D", "SX", "U"};
-            fprintf(stderr, "tk stamps (%s, mt %d nb %d): %llu workgroups, mean kernel time per workgroup %.1f us\n", backward ? "backward" : "forward", mt, nb, h[17],
-                    h[17] ? 0.01 * (double)h[16] / (double)h[17] : 0.0);
-            for (int t = 0; t < 4; ++t)
+            static const char* names[5] = {"SB", "D", "SX", "U", "UB"};
+            fprintf(stderr, "tk stamps (%s, mt %d nb %d): %llu workgroups, mean kernel time per workgroup %.1f us\n", backward ? "backward" : "forward", mt, nb, h[21],
+                    h[21] ? 0.01 * (double)h[20] / (double)h[21] : 0.0);
+            for (int t = 0; t < 5; ++t)
                 fprintf(stderr, "   %-2s items %6llu: wait %.2f us  body %.2f us  publish %.2f us per item; share of workgroup time: wait %.1f %% body %.1f %% publish %.1f %%\n", names[t],
                         h[t * 4 + 3], h[t * 4 + 3] ? 0.01 * h[t * 4] / h[t * 4 + 3] : 0.0, h[t * 4 + 3] ? 0.01 * h[t * 4 + 1] / h[t * 4 + 3] : 0.0,
-                        h[t * 4 + 3] ? 0.01 * h[t * 4 + 2] / h[t * 4 + 3] : 0.0, 100.0 * h[t * 4] / (double)h[16], 100.0 * h[t * 4 + 1] / (double)h[16], 100.0 * h[t * 4 + 2] / (double)h[16]);
-            unsigned long long z[20] = {};
+                        h[t * 4 + 3] ? 0.01 * h[t * 4 + 2] / h[t * 4 + 3] : 0.0, 100.0 * h[t * 4] / (double)h[20], 100.0 * h[t * 4 + 1] / (double)h[20], 100.0 * h[t * 4 + 2] / (double)h[20]);
+            unsigned long long z[24] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tk_stamps), z, sizeof(z));
         }
     }

@@ -328,48 +328,55 @@ def _replay_ticket_table(items, mt, nb, tail, backward):
     """Walk a ticket table in order with the kernel's own counters (csrc/trsm_tickets.hip): an item may start only if the wait
     condition the kernel polls already holds through items with LOWER tickets -- then no workgroup can ever wait on work nobody has
     started -- and at the end every tile has received every block column exactly once, in order."""
+    KQ = 4          # split items per (row tile, block column): 32 rows each
     ct = lambda J: tail if J == nb - 1 else 8
     ctiles = (nb - 1) * 8 + tail
     pos = (lambda J: nb - 1 - J) if backward else (lambda J: J)
     xd = np.zeros((mt, nb), np.int64); xs = np.zeros((mt, nb), np.int64); bs = np.zeros((mt, nb), np.int64)
     up = np.zeros((mt, ctiles), np.int64)
     seen = set()
+    big = 0
     for t, (word, r, cq, J) in enumerate(items):
         typ, npan = word & 15, (word >> 4) & 15
         key = (typ, r, cq, J)
         assert key not in seen, ("duplicate item", t, key)
         seen.add(key)
-        assert 0 <= r < mt and 0 <= J < nb
-        if typ == 3:    # update tile: panels J, J -/+ 1, ... (latest first)
-            assert 1 <= npan <= 4 and 0 <= cq < ctiles
+        assert r >= 0 and 0 <= J < nb
+        if typ in (3, 4):    # update: 128 x 128 tile (3) or the 2 x 2 group of tiles (2 r, 2 r + 1) x (2 cq, 2 cq + 1) (4); panels J, J -/+ 1, ...
+            rows = [r] if typ == 3 else [2 * r, 2 * r + 1]
+            cols = [cq] if typ == 3 else [2 * cq, 2 * cq + 1]
+            assert 1 <= npan <= 4 and rows[-1] < mt and cols[-1] < ctiles and cols[0] // 8 == cols[-1] // 8
+            big += typ == 4
             first = J + npan - 1 if backward else J - npan + 1      # earliest block column of the item
             assert 0 <= first < nb
-            Jt = cq // 8
+            Jt = cols[0] // 8
+            assert cols[-1] - 8 * Jt < ct(Jt)
             assert pos(J) < pos(Jt), ("an update from a block column that is not solved before its target", t)
-            assert xs[r, J] == 8, ("update before the split copy of its latest block column", t)
-            assert up[r, cq] == pos(first), ("update out of order", t, up[r, cq], pos(first))
             if npan > 1:
                 assert ct(J) == 8 and ct(first) == 8, ("a tail-width panel grouped with others", t)
-            up[r, cq] += npan
+            for rr in rows:
+                assert xs[rr, J] == KQ, ("update before the split copy of its latest block column", t)
+                for cc in cols:
+                    assert up[rr, cc] == pos(first), ("update out of order", t, up[rr, cc], pos(first))
+                    up[rr, cc] += npan
         elif typ == 1:  # diagonal-product tile
-            Jc = cq // 8
-            assert Jc == J and cq - 8 * J < ct(J)
-            assert bs[r, J] == 8, ("diagonal product before its operand is split", t)
+            assert r < mt and cq // 8 == J and cq - 8 * J < ct(J)
+            assert bs[r, J] == KQ, ("diagonal product before its operand is split", t)
             xd[r, J] += 1
         elif typ == 2:  # split of a solved block
-            assert 0 <= cq < 8 and xd[r, J] == ct(J), ("split of a block whose diagonal tiles are not all done", t)
+            assert r < mt and 0 <= cq < KQ and xd[r, J] == ct(J), ("split of a block whose diagonal tiles are not all done", t)
             xs[r, J] += 1
         else:           # split of an updated block
-            assert typ == 0 and 0 <= cq < 8
+            assert typ == 0 and r < mt and 0 <= cq < KQ
             for c in range(8 * J, 8 * J + ct(J)):
                 assert up[r, c] == pos(J), ("split of a block that has not received all its updates", t)
             bs[r, J] += 1
     for r in range(mt):
         for J in range(nb):
-            assert xd[r, J] == ct(J) and xs[r, J] == 8 and bs[r, J] == 8
+            assert xd[r, J] == ct(J) and xs[r, J] == KQ and bs[r, J] == KQ
             for c in range(8 * J, 8 * J + ct(J)):
                 assert up[r, c] == pos(J)
-    return len(items)
+    return len(items), big
 
 
 @pytest.mark.parametrize("mt,nb,tail,workers", [(8, 32, 8, 512), (1, 2, 8, 512), (2, 3, 1, 16), (29, 11, 5, 512), (8, 8, 8, 512),
@@ -387,8 +394,9 @@ def test_persistent_solve_ticket_tables_only_wait_on_lower_tickets(mt, nb, tail,
         buf = np.zeros((count.value, 4), np.int32)
         assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, buf.ctypes.data_as(ctypes.c_void_p), count.value,
                                           ctypes.byref(count)) == 0, lib.nngp_last_error()
-        n = _replay_ticket_table([tuple(int(v) for v in row) for row in buf], mt, nb, tail, bool(backward))
+        n, big = _replay_ticket_table([tuple(int(v) for v in row) for row in buf], mt, nb, tail, bool(backward))
         assert n == count.value
+        assert big > 0 or mt < 2 or nb < 4, "no 256 x 256 bulk items in a shape that has room for them"
         # the table is a pure function of the shape: run-to-run bitwise reproducibility of the solves depends on it
         buf2 = np.zeros_like(buf)
         assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, buf2.ctypes.data_as(ctypes.c_void_p), count.value,
