@@ -636,17 +636,18 @@ def main():
                 "timer": "HIP events on the caller's stream around each launch (library: nngp_model_residual_timer), timed steps only",
             }
         if stimer["on"] and stimer["solves"] > 0 and stimer["ms"] > 0.0:
-            # the kernel chain furthest below its pipe: the posterior's blocked triangular solves (split-float16 updates in steps of
-            # 1024 columns + float32 diagonal products), HIP events on the caller's stream around each solve
+            # the posterior's blocked triangular solves: one persistent, ticket-ordered launch each since round 5 (csrc/trsm_tickets.hip),
+            # HIP events on the caller's stream around each solve
             s_tf = stimer["flops"] / (stimer["ms"] * 1e-3) / 1e12
             result["roofline_solves"] = {
                 "bound": "mfma", "achieved": round(s_tf, 1), "peak": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
                 "frac": round(s_tf / (PEAK_F16_MFMA_TFLOPS / 3.0), 4),
-                "kernel": "blocked triangular solves of the posterior (k_gemm_nt_h3v2<LOWER=false> updates + k_gemm_nt_f32 diagonal products + "
-                          "k_split_rows_rowscale), N^2 M algorithmic flops per solve",
+                "kernel": "k_trsm_tickets: one persistent launch per blocked triangular solve of the posterior (256 x 256 split-float16 update "
+                          "tiles, 128 x 128 diagonal-product and chain tiles, row splits, all drawn from a ticket counter), N^2 M "
+                          "algorithmic flops per solve",
                 "solves_per_step": round(stimer["solves"] / args.steps, 2), "ms_per_step": round(stimer["ms"] / args.steps, 3),
-                "note": "a latency chain of N / 1024 steps with M / 256 tile rows per step (DESIGN.md section 8); the first solve of a fit "
-                        "shares the chip with the cut of K's digit planes, the last one with the alpha CG",
+                "note": "a dependency chain of N / 1024 block columns (DESIGN.md section 4); the solves share the chip with the alpha CG (from "
+                        "the predict's start) and the first two with the cut of K's digit planes",
                 "timer": "HIP events on the caller's stream around each solve (library: nngp_model_trsm_timer), timed steps only",
             }
         if shard_report is not None:

@@ -4,6 +4,7 @@
 //   gradient_descent_mse_ensemble(kernel_fn, X, Y, diag_reg) -> nngp_model_create / _fit
 //   predict_fn(x_test, get, compute_cov)                    -> nngp_model_predict
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <cmath>
 #include <new>
@@ -501,6 +502,7 @@ int i8s_cut_planes(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld,
 // costs the Cholesky exactly what the slicing takes, at any stream priority and wherever in the factorisation it starts -- its 32768
 // small workgroups settle on every compute unit a trailing-update launch has just left and the next launch waits for them -- and on
 // a CU-masked stream (1 / 2 / 4 units per XCD) it needs 95 / 64 / 55 ms: one compute unit moves ~20 GB/s of it.
+bool cg_from_the_start(const nngp_model* m, int64_t mp);
 int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kld, double* out, const double* cin, double beta,
                      double alpha, double* z, double gamma, int64_t mp, hipStream_t s, int grade) {
     const int64_t np = m->np;
@@ -529,7 +531,7 @@ int i8s_product_rows(nngp_model* m, I8Planes& pk, const double* kmat, int64_t kl
         const int64_t slab = mb * np;
         NNGP_TRY(launch_i8s_slice_rows(z + r0 * np, np, mb, np, ns_z, nullptr, w.zscale, w.zplanes, m->np_cap, (w.z_rows + 256) * m->np_cap, s,
                                        round_z ? z + r0 * np : nullptr));
-        if (r0 == 0 && grade == I8_COARSE && !m->gate_recorded && NNGP_KNOB(2) != 8 && NNGP_KNOB(2) != 9) {
+        if (r0 == 0 && grade == I8_COARSE && !m->gate_recorded && NNGP_KNOB(2) != 8 && NNGP_KNOB(2) != 9 && !cg_from_the_start(m, mp)) {
             // The deferred alpha CG (solve stream) starts HERE, not with the blocked solves before this product: its hundreds of small
             // GEMV launches settle on compute units between the solves' persistent split-float16 launches (which need a whole unit's
             // LDS) and cost them 3.7 ms at N = 32768 (scripts/cov_alone.py); beside this one long launch they fit the wave slots and
@@ -643,6 +645,20 @@ bool use_tickets(const nngp_model* m, int64_t mp) {
     return !m->tk_failed && m->tri.bs == 1024 && tk_usable(m->tk, mp, m->np) && NNGP_KNOB(9) != 16;
 }
 
+// With the blocked solves as persistent launches (224 registers, 128 KB of LDS: a 64-register kernel with a few KB of LDS fits beside
+// their workgroups) the deferred alpha CG no longer waits for the plane products' start: it runs from the predict's start on.
+bool cg_from_the_start(const nngp_model* m, int64_t mp) {
+    static const int env = getenv("NNGP_TK_GATE") ? atoi(getenv("NNGP_TK_GATE")) : 1;  // (development aid)
+    return env != 0 && use_split_solves(m, mp) && use_tickets(m, mp);
+}
+
+// While the digit planes of K are being cut on the solve stream (one 132 KB workgroup per compute unit: it cannot share a unit with a
+// persistent solve) the solves leave it some units; the alpha CG's light kernels fit beside the solve's workgroups as they are.
+int tickets_reserve(const nngp_model* m) {
+    static const int env = getenv("NNGP_TK_RESERVE") ? atoi(getenv("NNGP_TK_RESERVE")) : 0;  // (development aid; measured 0 / 32 / 48 / 64: posterior 29.8-30.1 / 30.1 / 30.3 / 29.8 ms at cfg3)
+    return m->i8_k_pending ? env : 0;
+}
+
 // a persistent solve that gave up waiting left its error word behind: report it once, and keep the model off that path
 int tickets_check(nngp_model* m, bool wait) {
     const int e = tk_poll_error(m->tk, wait);
@@ -691,7 +707,7 @@ static int apply_forward_untimed(nngp_model* m, int64_t mp, hipStream_t s) {
     if (NNGP_KNOB(7) == 1)  // timing experiment: the 128-wide recursion instead of the 1024-block form
         return trsm_rlt_f32(m->b32, m->np, mp, m->a32, m->ld, m->dinv, m->np, s);
     if (use_split_solves(m, mp)) {
-        if (use_tickets(m, mp)) return tk_solve(m->tk, m->b32, m->np, mp, m->np, m->split, false, s);
+        if (use_tickets(m, mp)) return tk_solve(m->tk, m->b32, m->np, mp, m->np, m->split, false, s, tickets_reserve(m));
         return trsm_rlt_blocks_h3(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, m->split, s);
     }
     return trsm_rlt_blocks_f32(m->b32, m->np, mp, m->a32, m->ld, m->tri, m->np, m->trsm_tmp, s);
@@ -721,7 +737,7 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
     int slot = -1;
     NNGP_TRY(trsm_timer_begin(m, mp, s, &slot));
     if (use_split_solves(m, mp) && use_tickets(m, mp))
-        NNGP_TRY(tk_solve(m->tk, m->b32, m->np, mp, m->np, m->split, true, s));
+        NNGP_TRY(tk_solve(m->tk, m->b32, m->np, mp, m->np, m->split, true, s, tickets_reserve(m)));
     else if (use_split_solves(m, mp))
         NNGP_TRY(trsm_rut_blocks_h3(m->b32, m->np, mp, m->lt_ready ? m->lt32 : nullptr, m->np, m->tri, m->np, m->trsm_tmp, m->split, s));
     else
@@ -1629,9 +1645,14 @@ static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t
         if (rc_i8 == 0 && !m->i8.k.ready) {
             if (m->ev_i8 == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_i8, hipEventDisableTiming));
             NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, s));  // K is complete; earlier readers of the planes are behind us
-            NNGP_HIP_CHECK(hipStreamWaitEvent(m->solve_stream, m->ev_i8, 0));
-            NNGP_TRY(i8s_cut_planes(m, m->i8.k, m->k64, m->ld, m->solve_stream));
-            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, m->solve_stream));
+            // With the alpha CG running from the predict's start (cg_from_the_start) the cut must not sit in front of it on the solve
+            // stream: it goes to the look-ahead's panel stream (idle between factorisations; the factor's inverted blocks were just
+            // queued there by tri_fork)
+            static const int cut_env = getenv("NNGP_TK_CUTSTREAM") ? atoi(getenv("NNGP_TK_CUTSTREAM")) : 1;  // (development aid)
+            hipStream_t cs = (cut_env != 0 && cg_from_the_start(m, mp) && m->la != nullptr && m->la->panel != nullptr) ? m->la->panel : m->solve_stream;
+            NNGP_HIP_CHECK(hipStreamWaitEvent(cs, m->ev_i8, 0));
+            NNGP_TRY(i8s_cut_planes(m, m->i8.k, m->k64, m->ld, cs));
+            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, cs));
             m->i8_k_pending = true;
         }
     }

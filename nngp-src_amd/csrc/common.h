@@ -333,7 +333,7 @@ int tk_prepare_inverses(TrsmTickets* tk, const TriInv& ti, int64_t np, hipStream
 bool tk_inverses_ready(const TrsmTickets* tk);
 void tk_invalidate_inverses(TrsmTickets* tk);
 bool tk_usable(const TrsmTickets* tk, int64_t m, int64_t np);
-int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, const SplitWork& sw, bool backward, hipStream_t s);
+int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, const SplitWork& sw, bool backward, hipStream_t s, int reserve_cus = 0);
 int tk_poll_error(TrsmTickets* tk, bool wait);
 int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int32_t* out, int64_t cap, int64_t* count);  // error word of a launch that gave up waiting (0: none seen)
 // y = (A + diag_add I) x for a SYMMETRIC n x n float64 matrix stored in full, reading only its lower triangle (half the bytes

@@ -116,7 +116,7 @@ constexpr int HSTAGE2 = 2 * HT2 * TROW;  // its stage: A rows + B rows, 64 KB
 // the dependency chain (diagonal products, the last update of a block column before it is solved) stay 128 x 128 tiles on waves 0-3
 // with a four-stage ring: they are latency, not bandwidth.
 __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
-    __shared__ __attribute__((aligned(1024))) char smem[160 * 1024];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
+    __shared__ __attribute__((aligned(1024))) char smem[128 * 1024];  // ONE object (gemm_h3.hip: a second one drains the LDS-DMA queue)
     int& s_word = *reinterpret_cast<int*>(smem);                      // ticket / wait status: only touched between items
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -308,12 +308,8 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
             glds_a(0);
             // acc[i][j][e] = tile(group*128 + 16 i + r16, w4*64 + 16 j + 4 q4 + e): the lane's rows 16 i + r16 of its group's 128
             const int row_base = r * HT2 + group * 128;
-            float rs_cur[8];
-            {
-                const float* rv = P.rinv_x + (int64_t)J * P.r_stride + row_base + r16;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rs_cur[i] = rv[16 * i];
-            }
+            // (the rows' scales are re-read where they are needed -- at block-column boundaries and in the epilogue -- rather than held:
+            // eight registers that decide whether a light kernel of another stream fits beside this one on the compute unit)
             f32x4v acc[8][4];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -331,13 +327,12 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
                     // block-column boundary: the sums so far carry the row scales of block column pcur, the terms to come those of the
                     // next one (ratios of powers of two: exact).  The scale loads wait for everything in flight: once per 32 stages.
                     next_bound += nkp;
+                    const float* rc = P.rinv_x + (int64_t)(P.backward ? J + pcur : J - pcur) * P.r_stride + row_base + r16;
                     ++pcur;
                     const float* rv = P.rinv_x + (int64_t)(P.backward ? J + pcur : J - pcur) * P.r_stride + row_base + r16;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float nxt = rv[16 * i];
-                        const float f = rs_cur[i] / nxt;
-                        rs_cur[i] = nxt;
+                        const float f = rc[16 * i] / rv[16 * i];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -425,6 +420,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
             const unsigned voff = ((unsigned)r16 * (unsigned)P.ldb + 4u * (unsigned)q4) * 4u;
             char* cw = reinterpret_cast<char*>(P.b + (int64_t)row_base * P.ldb + (int64_t)cq * HT2 + w4 * 64);
             const int64_t band = (int64_t)16 * P.ldb * 4;
+            const float* rs_last = P.rinv_x + (int64_t)(P.backward ? J + pcur : J - pcur) * P.r_stride + row_base + r16;
 #pragma unroll
             for (int ib = 0; ib < 8; ib += 2) {
                 f32x4v cold[2][4];
@@ -434,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
                     for (int j = 0; j < 4; ++j) cold[i][j] = *reinterpret_cast<const f32x4v*>(cw + (ib + i) * band + voff + 64 * j);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const float fs = -rs_cur[ib + i] * P.l_iscale;
+                    const float fs = -rs_last[16 * (ib + i)] * P.l_iscale;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1000,7 +996,7 @@ bool tk_usable(const TrsmTickets* tk, int64_t m, int64_t np) {
 }
 
 // B[m, np] <- B L^-T (backward = false; sw.planes) or B L^-1 (backward = true; sw.planes_t) in one launch
-int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, const SplitWork& sw, bool backward, hipStream_t s) {
+int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, const SplitWork& sw, bool backward, hipStream_t s, int reserve_cus) {
     NNGP_REQUIRE(tk_usable(tk, m, np), "tk_solve: not usable for m=%lld np=%lld", (long long)m, (long long)np);
     NNGP_REQUIRE(sw.k_cap == kBs && (backward ? (sw.planes_t != nullptr && sw.lt_ready) : (sw.planes != nullptr && sw.l_ready)),
                  "tk_solve: split copy of the factor not available");
@@ -1042,7 +1038,9 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     // the error word survives (sticky until the host has read it); ticket and counters restart
     NNGP_HIP_CHECK(hipMemsetAsync(tk->sync, 0, sizeof(int) * SY_ERROR, s));
     NNGP_HIP_CHECK(hipMemsetAsync(tk->sync + SY_ERROR + 1, 0, sizeof(int) * (used - SY_ERROR - 1), s));
-    int grid = tk->workers;
+    // reserve_cus: compute units left to a kernel of another stream that needs whole units (the cut of K's digit planes: 132 KB of LDS
+    // per workgroup); the table was scheduled for all of them, which only costs fidelity of the simulated order
+    int grid = tk->workers - (reserve_cus > 0 && reserve_cus < tk->workers / 2 ? reserve_cus : 0);
     if (grid > P.n_items) grid = P.n_items;
     hipLaunchKernelGGL(k_trsm_tickets, dim3((unsigned)grid), dim3(512), 0, s, P);
     NNGP_HIP_CHECK(hipGetLastError());
