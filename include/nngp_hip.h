@@ -167,6 +167,14 @@ int nngp_model_precond(nngp_model* m, const double* r, double* z, void* stream);
 int nngp_model_matvec_rows(nngp_model* m, const double* p, double* q, int64_t row_begin, int64_t row_end, void* stream);
 int nngp_model_set_alpha(nngp_model* m, const double* alpha, int32_t iters, double rel_residual, void* stream);
 int nngp_model_info(nngp_model* m, nngp_fit_info* info /* host */);
+/* Ownership rule of SURVEY.md 8b ("allocated in nngp_fit, never inside timed launch functions") for the predict side: allocates, now,
+ * everything an nngp_model_predict of up to `rows` test rows with this cov_mode would otherwise allocate on first use (cross-kernel
+ * and right-hand-side blocks, the workspace of the blocked solves, refinement rows, the digit planes and products of the int8
+ * residual path, the float32 path's L^T, the full-covariance blocks).  nngp_model_create(m_cap > 0) covers the mean-only part;
+ * the Python GPModel calls this with (m_cap, NNGP_COV_DIAG).  nngp_alloc_count(): device allocations the library has made so far
+ * in this process (diagnostic: a predict on a reserved model adds none -- tests/test_gpu_api.py). */
+int nngp_model_reserve(nngp_model* m, int64_t rows, int32_t cov_mode);
+int64_t nngp_alloc_count(void);
 /* Live timing of the path's dominant kernel, the split-float16 trailing update of the Cholesky (k_gemm_nt_h3, lower):
  * with the timer on, nngp_model_factor brackets every such launch with a pair of HIP events on the stream it is launched
  * on (bench.py's `roofline` object; no reference counterpart -- the reference prints wall-clock seconds, train.py:176,195).

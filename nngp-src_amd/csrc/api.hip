@@ -36,11 +36,15 @@ int make_arch_dev(const nngp_arch* arch, ArchDev* out) {
     return 0;
 }
 
+std::atomic<long long> g_alloc_count{0};  // device allocations made by the library so far (nngp_alloc_count)
+void note_alloc() { g_alloc_count.fetch_add(1, std::memory_order_relaxed); }
+
 template <typename T>
 static int dev_alloc(T** p, int64_t count) {
     *p = nullptr;
     if (count <= 0) return 0;
     NNGP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)count));
+    g_alloc_count.fetch_add(1, std::memory_order_relaxed);
     return 0;
 }
 
@@ -342,14 +346,17 @@ int ensure_refine_capacity(nngp_model* m, int64_t mp) {
     return 0;
 }
 
-// L^T and the transposed inverted diagonal blocks: operands of the "B L^-1" half of (L L^T)^-1.
+// L^T and the transposed inverted diagonal blocks: operands of the "B L^-1" half of (L L^T)^-1 on the float32 path.
+int ensure_lt_alloc(nngp_model* m) {
+    if (m->lt32 != nullptr) return 0;
+    NNGP_HIP_CHECK(hipDeviceSynchronize());
+    NNGP_TRY(dev_alloc(&m->lt32, m->np_cap * m->np_cap));
+    NNGP_TRY(dev_alloc(&m->dinvt, (m->np_cap / TB) * TB * TB));
+    return 0;
+}
 int ensure_lt(nngp_model* m, hipStream_t s) {
     if (m->lt_ready) return 0;
-    if (m->lt32 == nullptr) {
-        NNGP_HIP_CHECK(hipDeviceSynchronize());
-        NNGP_TRY(dev_alloc(&m->lt32, m->np_cap * m->np_cap));
-        NNGP_TRY(dev_alloc(&m->dinvt, (m->np_cap / TB) * TB * TB));
-    }
+    NNGP_TRY(ensure_lt_alloc(m));
     NNGP_TRY(launch_transpose_f32(m->a32, m->ld, m->lt32, m->np, m->np, s));
     NNGP_TRY(launch_transpose_blocks_f32(m->dinv, m->dinvt, TB, m->np / TB, s));
     m->lt_ready = true;
@@ -410,6 +417,7 @@ int i8s_planes_policy(const nngp_model* m) {
 
 template <typename T>
 static bool soft_alloc(T** p, int64_t count) {  // false (and no sticky error) when the device has no room
+    g_alloc_count.fetch_add(1, std::memory_order_relaxed);
     *p = nullptr;
     if (NNGP_KNOB(5) == 55) return false;  // test: as if the device were full
     if (hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)count) == hipSuccess) return true;
@@ -732,8 +740,13 @@ int apply_inverse_f32(nngp_model* m, int64_t mp, hipStream_t s) {
         m->gate_recorded = true;
     }
     if (lt_aside) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_lt, 0));
-    if (NNGP_KNOB(7) == 1) return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+    // (whoever gets here on the float32 path finds its operand built: round 4's null-pointer abort came from a caller that had not)
+    if (NNGP_KNOB(7) == 1) {
+        NNGP_TRY(ensure_lt(m, s));
+        return trsm_rut_f32(m->b32, m->np, mp, m->lt32, m->np, m->dinvt, m->np, s);
+    }
     if (use_split_solves(m, mp)) NNGP_TRY(ensure_lt_split(m, s));
+    else NNGP_TRY(ensure_lt(m, s));
     int slot = -1;
     NNGP_TRY(trsm_timer_begin(m, mp, s, &slot));
     if (use_split_solves(m, mp) && use_tickets(m, mp))
@@ -974,6 +987,32 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
     return 0;
 }
 
+int64_t nngp_alloc_count(void) { return (int64_t)g_alloc_count.load(std::memory_order_relaxed); }
+
+// Everything a predict of up to `rows` test rows with this covariance mode allocates lazily otherwise (workspace is
+// allocated ahead, never inside the timed launch functions): cross-kernel / right-hand-side buffers, the persistent solves'
+// workspace, the refinement rows, the int8 path's digit planes and products, the float32 path's L^T, the full-covariance blocks.
+int nngp_model_reserve(nngp_model* m, int64_t rows, int32_t cov_mode) {
+    NNGP_REQUIRE(m != nullptr && rows > 0 && cov_mode >= NNGP_COV_NONE && cov_mode <= NNGP_COV_FULL, "reserve: bad arguments");
+    NNGP_TRY(ensure_predict_capacity(m, rows, true));
+    if (cov_mode == NNGP_COV_NONE) return 0;
+    const int64_t mp = round_up(rows, TB);
+    if (m->var_refine >= 1 || m->get == NNGP_GET_NTK) NNGP_TRY(ensure_refine_capacity(m, mp));
+    const bool split_path = m->split.planes != nullptr && mp <= m->split.mb_cap && mp >= 256 && mp * m->np_cap >= 7000000;
+    if (!split_path) NNGP_TRY(ensure_lt_alloc(m));
+    if (m->np_cap >= 2048 && mp >= 256 && !m->i8_unavailable && (m->var_refine >= 1 || m->get == NNGP_GET_NTK)) {
+        if (cov_mode == NNGP_COV_FULL && m->np_cap >= 4096 && mp >= 512) m->i8_want_fine = true;
+        const int rc = ensure_i8s(m, mp, m->i8.k, i8s_planes_policy(m));
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 0 && m->i8_guard == nullptr) {  // the guard's word and its pinned mirror (level-1 variances)
+            NNGP_TRY(dev_alloc(&m->i8_guard, 1));
+            NNGP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->i8_guard_host), sizeof(unsigned long long), hipHostMallocDefault));
+        }
+    }
+    if (cov_mode == NNGP_COV_FULL) NNGP_TRY(ensure_full_cov_capacity(m, rows));
+    return 0;
+}
+
 int nngp_model_destroy(nngp_model* m) {
     if (m) {
         (void)hipDeviceSynchronize();
@@ -1105,6 +1144,7 @@ int nngp_model_factor_input_rows(nngp_model* m, int64_t row_begin, int64_t row_e
 
 int nngp_model_factor_input_complete(nngp_model* m) {
     NNGP_REQUIRE(m != nullptr && m->built, "factor_input_complete: build the kernel rows first");
+    NNGP_REQUIRE(m->k64_partial, "factor_input_complete: no rows of the factor input were converted (nngp_model_factor_input_rows) since the last build");
     m->a32_complete = true;
     return 0;
 }
@@ -1203,6 +1243,7 @@ double nngp_model_factor_shift(nngp_model* m) { return m != nullptr ? m->reg_fac
 int nngp_model_append(nngp_model* m, const double* x_new, const double* y_new, int64_t b, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->factored, "append: fit the model first");
+    NNGP_REQUIRE(!m->k64_partial, "append: not with the row-sharded layout (the model holds only its own kernel rows)");
     NNGP_REQUIRE(x_new != nullptr && y_new != nullptr && b > 0, "append: bad arguments");
     NNGP_REQUIRE(m->n + b <= m->n_cap, "append: %lld + %lld rows exceed n_cap = %lld", (long long)m->n, (long long)b,
                  (long long)m->n_cap);
@@ -1369,6 +1410,8 @@ static int run_pending_solve(nngp_model* m, hipStream_t user, bool order_user, b
 int nngp_model_solve(nngp_model* m, int32_t max_iters, double tol, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->factored, "solve: factor first");
+    NNGP_REQUIRE(!m->k64_partial, "solve: this model holds only its own kernel rows (row-sharded layout): the caller drives the CG "
+                                  "(nngp_model_precond, nngp_model_matvec_rows) and hands alpha back with nngp_model_set_alpha");
     NNGP_TRY(drop_pending_solve(m));
     // default: 60 iterations; a factor with a raised shift preconditions worse by ~ sqrt(reg_fac / reg)
     const double weak = (m->reg > 0.0 && m->reg_fac > m->reg) ? sqrt(m->reg_fac / m->reg) : 1.0;
@@ -1551,6 +1594,7 @@ int nngp_model_set_refine(nngp_model* m, int32_t sweeps) {
 int nngp_model_prepare_serving(nngp_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     NNGP_REQUIRE(m != nullptr && m->solved, "prepare_serving: fit the model first");
+    NNGP_REQUIRE(!m->k64_partial, "prepare_serving: not with the row-sharded layout (the model holds only its own kernel rows)");
     if (m->get != NNGP_GET_NNGP) return 0;  // the NTK covariance has no second-order formula to absorb the inverse's error
     NNGP_TRY(run_pending_solve(m, s, true));  // its iteration count says how good the preconditioner is
     const int64_t n = m->n, np = m->np;
@@ -1608,6 +1652,9 @@ static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t
     const bool on_train = (x_test == nullptr);
     if (on_train) mt = m->n;
     NNGP_REQUIRE(mt >= 0, "predict: negative row count");
+    NNGP_REQUIRE(!m->k64_partial || (cov_mode == NNGP_COV_NONE && !on_train),
+                 "predict: this model holds only its own kernel rows (row-sharded layout): it serves means of test rows; covariances are "
+                 "formed by the caller from nngp_model_apply_factor and its row block (shard32.py)");
     if (mt == 0) return 0;
     const bool is_ntk = (m->get == NNGP_GET_NTK);
     const int64_t n = m->n, np = m->np, mp = round_up(mt, TB);
@@ -1775,8 +1822,8 @@ static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t
                 if (m->i8_guard == nullptr) {
                     NNGP_TRY(dev_alloc(&m->i8_guard, 1));
                     NNGP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m->i8_guard_host), sizeof(unsigned long long), hipHostMallocDefault));
-                    NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_guard, hipEventDisableTiming));
                 }
+                if (m->ev_guard == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_guard, hipEventDisableTiming));
                 NNGP_HIP_CHECK(hipMemsetAsync(m->i8_guard, 0, sizeof(unsigned long long), s));
                 NNGP_TRY(launch_i8s_floor_ratio_rows(m->rows.zstat, mt, var_or_cov, pl, m->i8.ns_z, m->i8.ns_k, m->i8.k.scale + m->np_cap,
                                                      m->i8_guard, s));

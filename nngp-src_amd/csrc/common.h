@@ -13,6 +13,7 @@ namespace nngp {
 constexpr int TB = 128;  // Cholesky / GEMM tile edge; all float32 device matrices are padded to it
 
 void set_error(const char* fmt, ...);
+void note_alloc();  // counts a device allocation (nngp_alloc_count)
 // Timing-experiment switches.  They exist ONLY in libnngp_hip_knobs.so (built with -DNNGP_TIMING_KNOBS for scripts/ and the
 // A/B tests, entry point nngp_debug_set); in the product library NNGP_KNOB(i) is the constant 0 and every branch on it is
 // compiled out.  Keys:

@@ -925,7 +925,7 @@ int tk_create(TrsmTickets** out, int64_t np_cap, int64_t m_cap) {
     tk->sync_ints = SY_COUNTERS + 3 * mt * nb + mt * nb * 8;
     tk->items_cap = tk_items_bound(mt, nb);
     bool ok = true;
-    auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } };
+    auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } note_alloc(); };
     A((void**)&tk->planes_x, (size_t)nb * tk->m_cap * kLdp);
     A((void**)&tk->planes_d, (size_t)nb * tk->m_cap * kLdp);
     A((void**)&tk->rinv_x, sizeof(float) * nb * tk->m_cap);

@@ -31,6 +31,8 @@ class GPModel:
         self._check(self.lib.nngp_model_create(ctypes.byref(self.handle), int(n_cap), int(m_cap), int(d), int(ny),
                                               ctypes.byref(self.arch), _GET[get], float(diag_reg),
                                               int(bool(diag_reg_absolute_scale))))
+        if m_cap > 0:  # predict-side workspace now, not inside the first predict (SURVEY 8b ownership rule)
+            self._check(self.lib.nngp_model_reserve(self.handle, int(m_cap), _lib.COV_DIAG))
         self.n = 0
         self._diag_reg, self._absolute = float(diag_reg), bool(diag_reg_absolute_scale)
         self._keep = []  # device tensors that must outlive asynchronous work
@@ -137,6 +139,11 @@ class GPModel:
         assert b.is_cuda and b.dtype == torch.float32 and b.is_contiguous() and b.dim() == 2
         self._check(self.lib.nngp_model_apply_factor(self.handle, b.data_ptr(), b.shape[0], 1 if both_halves else 0, _lib.stream_ptr()))
         return b
+
+    def reserve(self, rows: int, cov="diag"):
+        """Allocate now what a predict of up to ``rows`` test rows with this covariance mode would allocate on first use."""
+        self._check(self.lib.nngp_model_reserve(self.handle, int(rows), _COV[cov]))
+        return self
 
     def solve(self, max_iters: int = 0, tol: float = 0.0):
         self._check(self.lib.nngp_model_solve(self.handle, int(max_iters), float(tol), _lib.stream_ptr()))

@@ -653,3 +653,131 @@ def test_int8_residual_path_against_the_float64_residual():
     ntk.debug_set(5, 0)
     assert np.max(np.abs(v_i8 - v_64) / np.abs(v_64)) < 1e-7
     ntk.close()
+
+
+def test_row_sharded_layout_refuses_what_it_cannot_serve():
+    """Round-4 advice: after nngp_model_factor_input_rows the model's float64 kernel holds this rank's rows only (shard32.py; the
+    nt.batch device slot of train.py:166-168) -- a covariance, a replicated CG, an appended fit or a serving inverse computed from it
+    would be silently wrong.  They must come back as error codes; the mean of test rows (alpha installed by the caller) still works."""
+    import ctypes
+    from nngp_src_amd import _lib
+    lib = _lib.load()
+    n, d = 2304, 16
+    x, y = synth.synthetic_queries(n, d, seed=3)
+    xt, _ = synth.synthetic_queries(256, d, seed=4)
+    model = GPModel(n + 128, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3)
+    h, s, p = model.handle, _lib.stream_ptr(), _lib.ptr
+
+    def failed(rc, needle):
+        msg = (lib.nngp_last_error() or b"").decode()
+        return rc < 0 and needle in msg, (rc, msg)
+
+    model.set_train(x, y)
+    model.build_rows(0, n)
+    ok, info = failed(lib.nngp_model_factor_input_complete(h), "no rows of the factor input")
+    assert ok, info
+    assert lib.nngp_model_factor_input_rows(h, 0, n, 1.0, s) == 0
+    assert lib.nngp_model_factor_input_complete(h) == 0
+    model.factor()
+    ok, info = failed(lib.nngp_model_solve(h, 0, 0.0, s), "row-sharded")
+    assert ok, info
+    # alpha from the single-GPU fit of the same data stands in for the caller's sharded CG
+    ref = GPModel(n, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    alpha = ref.alpha().contiguous()
+    mean_ref = ref.predict(xt, cov=None)
+    assert lib.nngp_model_set_alpha(h, p(alpha), 5, 1e-11, s) == 0
+    xd = _lib.to_device_f64(xt)
+    mean = torch.empty((256, 1), dtype=torch.float64, device=G.dev())
+    var = torch.empty((256,), dtype=torch.float64, device=G.dev())
+    for mode in (_lib.COV_DIAG, _lib.COV_FULL):
+        ok, info = failed(lib.nngp_model_predict(h, p(xd), 256, mode, p(mean), p(var), s), "row-sharded")
+        assert ok, info
+    ok, info = failed(lib.nngp_model_predict(h, None, 0, _lib.COV_NONE, p(mean), None, s), "row-sharded")   # x_test=None reads K_dd as the cross kernel
+    assert ok, info
+    ok, info = failed(lib.nngp_model_prepare_serving(h, s), "row-sharded")
+    assert ok, info
+    xn = _lib.to_device_f64(x[:64]); yn = _lib.to_device_f64(y[:64])
+    ok, info = failed(lib.nngp_model_append(h, p(xn), p(yn), 64, s), "row-sharded")
+    assert ok, info
+    assert lib.nngp_model_predict(h, p(xd), 256, _lib.COV_NONE, p(mean), None, s) == 0
+    assert G.mean_gate(mean.cpu().numpy(), mean_ref)[0] < 1e-9
+    model.close(); ref.close()
+
+
+@pytest.mark.parametrize("n,rows", [(2500, 300), (9300, 384)])
+def test_every_entry_point_on_a_fresh_fit_in_an_unusual_order(n, rows):
+    """Round 4 lost a GPU session to a null device pointer: nngp_model_apply_factor(both halves) reached the float32 solve path before
+    anything had built L^T.  The operand is now built by the function that reads it (apply_inverse_f32), so no order of calls can
+    reach it unbuilt.  A freshly created and fitted model takes every public entry point here in an order no other test uses --
+    both halves of the factor FIRST -- and must answer with results or error codes, never with a fault (include/nngp_hip.h: error
+    behaviour).  n = 2500: the float32 solve path; n = 9300, 384 rows: the persistent float16-pipe solves."""
+    import ctypes
+    import scipy.linalg as sla
+    from nngp_src_amd import _lib
+    lib = _lib.load()
+    d = 12
+    x, y = synth.synthetic_queries(n, d, seed=21)
+    xt, _ = synth.synthetic_queries(rows, d, seed=22)
+    model = GPModel(n + 256, d, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    h, s, p = model.handle, _lib.stream_ptr(), _lib.ptr
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((rows, n)).astype(np.float32)
+    Z = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev()), both_halves=True).cpu().numpy().astype(np.float64)   # first call on the handle
+    a32, _ = model.factor_buffers()
+    L = torch.tril(a32[:n, :n]).double().cpu().numpy()
+    Zref = sla.cho_solve((L, True), B.astype(np.float64).T).T
+    assert np.linalg.norm(Z - Zref) <= 5e-3 * np.linalg.norm(Zref)
+    r = torch.from_numpy(rng.standard_normal(n)).to(G.dev())
+    z = torch.empty_like(r)
+    assert lib.nngp_model_precond(h, p(r), p(z), s) == 0
+    q = torch.empty((100,), dtype=torch.float64, device=G.dev())
+    assert lib.nngp_model_matvec_rows(h, p(r), p(q), 50, 150, s) == 0
+    model.set_refine(2)
+    mean2, var2 = model.predict(xt, cov="diag")
+    model.set_refine(0)
+    mean0, var0 = model.predict(xt, cov="diag")
+    model.set_refine(1)
+    mean1, cov1 = model.predict(xt, cov="full")
+    assert np.allclose(mean0, mean2, rtol=0, atol=1e-8 * np.abs(mean2).max()) and np.allclose(np.diag(cov1), var2, rtol=1e-4)
+    assert np.allclose(var0, var2, rtol=5e-2)
+    model.prepare_serving()
+    mean_s, var_s = model.predict(xt, cov="diag")
+    assert np.allclose(var_s, var2, rtol=1e-4)
+    X1 = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev())).cpu().numpy().astype(np.float64)
+    assert np.isfinite(X1).all()
+    xa, ya = synth.synthetic_queries(200, d, seed=23)
+    model.append(xa, ya)
+    mean_a, var_a = model.predict(xt, cov="diag")
+    assert np.isfinite(mean_a).all() and (var_a > 0).all()
+    Z2 = model.apply_factor(torch.from_numpy(np.ascontiguousarray(rng.standard_normal((rows, n + 200)).astype(np.float32))).to(G.dev()), both_halves=True)
+    assert torch.isfinite(Z2).all()
+    assert model.info()["clamped_pivots"] == 0
+    model.close()
+
+
+def test_predicts_on_a_reserved_model_allocate_nothing():
+    """SURVEY.md 8b ownership rule (workspace is allocated ahead, never inside the timed launch functions): a model created with
+    m_cap -- GPModel then calls nngp_model_reserve(m_cap, diag) -- makes no device allocation in its first predict after a fit, nor
+    in its tenth, nor after a refit; nngp_alloc_count is the library's own count of its hipMalloc calls."""
+    from nngp_src_amd import _lib
+    lib = _lib.load()
+    n, d, mrows = 4352, 16, 512
+    x, y = synth.synthetic_queries(n, d, seed=8)
+    xt, _ = synth.synthetic_queries(mrows, d, seed=9)
+    model = GPModel(n, d, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], diag_reg=1e-3, m_cap=mrows)
+    xd = _lib.to_device_f64(xt)
+    model.fit(x, y)
+    torch.cuda.synchronize()
+    c0 = lib.nngp_alloc_count()
+    assert c0 > 0
+    first = model.predict(xd, cov="diag")
+    assert lib.nngp_alloc_count() == c0, "the first predict after a fit allocated device memory"
+    for _ in range(9):
+        last = model.predict(xd, cov="diag")
+    assert lib.nngp_alloc_count() == c0, "a later predict allocated device memory"
+    assert np.array_equal(first[0], last[0]) and np.array_equal(first[1], last[1])
+    model.fit(x, y)
+    model.predict(xd, cov="diag")
+    model.predict(xd[:300], cov="diag")
+    assert lib.nngp_alloc_count() == c0, "a refit or a smaller batch allocated device memory"
+    model.close()
