@@ -215,7 +215,7 @@ struct nngp_model {
         dev_free(i8.k.planes); dev_free(i8.k.scale); dev_free(i8.aux.planes); dev_free(i8.aux.scale); dev_free(i8.zplanes);
         for (int t = 0; t < I8Work::kMaxTimed; ++t) { if (i8.t0[t]) (void)hipEventDestroy(i8.t0[t]); if (i8.t1[t]) (void)hipEventDestroy(i8.t1[t]); } dev_free(i8.zscale); dev_free(i8.partial); dev_free(i8.rowpart); dev_free(i8.counters);
         dev_free(split.planes); dev_free(split.counters); dev_free(split.planes_t); dev_free(split.planes_b); dev_free(split.row_inv);
-        dev_free(split.ldiag); dev_free(split.dfrag);
+        dev_free(split.ldiag); dev_free(split.dfrag); dev_free(split.dscale);
         tk_destroy(tk);
         dev_free(xt_q); dev_free(tt_diag); dev_free(ktd64); dev_free(b32); dev_free(trsm_tmp); dev_free(ktt64); dev_free(vvt32);
         dev_free(lt32); dev_free(dinvt); dev_free(z64); dev_free(r64); dev_free(covp64); dev_free(kaux64); dev_free(ktd_aux);
@@ -977,6 +977,7 @@ int nngp_model_create(nngp_model** out, int64_t n_cap, int64_t m_cap, int32_t d,
         if (rc == 0 && !soft_alloc(&m->split.planes_t, ncols * m->split.col_stride)) m->split.planes_t = nullptr;  // (no room: built lazily, or float32 path)
         if (rc == 0) rc = dev_alloc(&m->split.ldiag, 2 * kLookAheadNb * kLookAheadNb * 4);
         if (rc == 0) rc = dev_alloc(&m->split.dfrag, 2 * kLookAheadNb * 128);
+        if (rc == 0) rc = dev_alloc(&m->split.dscale, 2 * kLookAheadNb);
     }
     if (rc == 0 && m_cap > 0) rc = ensure_predict_capacity(m, m_cap, true);
     if (rc != 0) {

@@ -157,10 +157,10 @@ int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int6
                           char* planes, int64_t ldp, float scale, hipStream_t s, char* planes_t = nullptr, int64_t tstride = 0,
                           int64_t row0 = 0, int64_t col0 = 0);
 int launch_split_diag_frag(const float* a, int64_t ld, int64_t w, float scale, char* out, const float* dinv, float* dfrag,
-                           hipStream_t s);
-int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, int64_t w, char* planes,
-                         int64_t ldp, float scale, hipStream_t s, char* planes_t = nullptr, int64_t tstride = 0, int64_t row0 = 0,
-                         int64_t col0 = 0);
+                           float* dscale, hipStream_t s);  // dfrag: split halves of the inverted 128-blocks in fragment order; dscale: their rows' 1 / scale
+int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dfrag, const float* dscale, int64_t w,
+                         char* planes, int64_t ldp, float scale, hipStream_t s, char* planes_t = nullptr, int64_t tstride = 0,
+                         int64_t row0 = 0, int64_t col0 = 0);
 
 
 struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one per model
@@ -173,7 +173,8 @@ struct SplitWork {   // float16-split copies of the factor (gemm_h3.hip); one pe
     bool l_ready = false;      // every block column of the current factor has been written
     int64_t split_panel = -1;  // block-column offset whose split copy was last written by the block-column ABI
     char* ldiag = nullptr;     // 2 x 4 k_cap^2 bytes: split copy of the diagonal block being solved against, in the fragment order of k_trsm_panel_h3
-    float* dfrag = nullptr;    // 2 x k_cap x 128 floats: its inverted 128-blocks in the same fragment order
+    float* dfrag = nullptr;    // 2 x k_cap x 128 floats: its inverted 128-blocks in the same fragment order (round 5: as split halves)
+    float* dscale = nullptr;   // 2 x k_cap floats: 1 / scale of every row of those blocks
                                // (two of each, by block-column parity: the bulk rows of block column k are still being solved on the
                                // solve stream of the grouped Cholesky while the panel stream prepares block column k + 1)
     char* planes_t = nullptr;  // same shape: L^T by block row j, rows r < j*k_cap (built on the first posterior solve)

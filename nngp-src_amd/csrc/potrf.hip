@@ -856,9 +856,9 @@ static int potrf_lookahead_grouped(float* a, int64_t n, int64_t ld, float* dinv,
         char* pt = (sw->planes_t != nullptr && nb == sw->k_cap && NNGP_KNOB(9) != 8) ? sw->planes_t : nullptr;
         wrote_t = wrote_t && pt != nullptr;
         if (k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr) {
-            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, la->update);
+            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, sw->dscale, la->update);
             if (rc == 0)
-                rc = launch_trsm_panel_h3(below, ld, m, sw->ldiag, sw->dfrag, nbk, pk_rows, ldp, sw->scale, la->update, pt, sw->col_stride, o + nbk, o);
+                rc = launch_trsm_panel_h3(below, ld, m, sw->ldiag, sw->dfrag, sw->dscale, nbk, pk_rows, ldp, sw->scale, la->update, pt, sw->col_stride, o + nbk, o);
         } else {
             rc = launch_trsm_panel_f32(below, ld, m, akk, ld, dk, nbk, pk_rows, ldp, sw->scale, la->update, pt, sw->col_stride, o + nbk, o);
         }
@@ -1133,9 +1133,10 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
         const bool solve_h3 = k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr;
         char* ldiag = sw->ldiag + (int64_t)(k & 1) * 4 * sw->k_cap * sw->k_cap;
         float* dfrag = sw->dfrag + (int64_t)(k & 1) * sw->k_cap * 128;
+        float* dscale = sw->dscale + (int64_t)(k & 1) * sw->k_cap;
         if (solve_h3) {
-            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, ldiag, dk, dfrag, SP);
-            if (rc == 0) rc = launch_trsm_panel_h3(below, ld, nb2, ldiag, dfrag, nbk, pk_rows, ldp, sw->scale, SP);
+            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, ldiag, dk, dfrag, dscale, SP);
+            if (rc == 0) rc = launch_trsm_panel_h3(below, ld, nb2, ldiag, dfrag, dscale, nbk, pk_rows, ldp, sw->scale, SP);
         } else {
             rc = launch_trsm_panel_f32(below, ld, nb2, akk, ld, dk, nbk, pk_rows, ldp, sw->scale, SP);
         }
@@ -1145,7 +1146,7 @@ static int potrf_lookahead_grouped_v4(float* a, int64_t n, int64_t ld, float* di
             NNGP_HIP_CHECK(hipStreamWaitEvent(SB, la->ev_tc[k], 0));
             if (ev_rows != nullptr) NNGP_HIP_CHECK(hipStreamWaitEvent(SB, ev_rows, 0));
             if (solve_h3)
-                rc = launch_trsm_panel_h3(below + nb2 * ld, ld, m - nb2, ldiag, dfrag, nbk, pk_rows + nb2 * ldp, ldp, sw->scale, SB);
+                rc = launch_trsm_panel_h3(below + nb2 * ld, ld, m - nb2, ldiag, dfrag, dscale, nbk, pk_rows + nb2 * ldp, ldp, sw->scale, SB);
             else
                 rc = launch_trsm_panel_f32(below + nb2 * ld, ld, m - nb2, akk, ld, dk, nbk, pk_rows + nb2 * ldp, ldp, sw->scale, SB);
             if (rc != 0) break;
@@ -1332,8 +1333,8 @@ int potrf_lookahead_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* c
         // data, see below.  Debug key 2 = 5: float32 everywhere.)
         const bool solve_h3 = fused && planes_here && k > 0 && nbk == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr && NNGP_KNOB(2) != 5;
         if (solve_h3) {
-            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, la->update);
-            if (rc == 0) rc = launch_trsm_panel_h3(akk + nbk * ld, ld, m, sw->ldiag, sw->dfrag, nbk, pk_rows, ldp, sw->scale, la->update);
+            rc = launch_split_diag_frag(akk, ld, nbk, sw->scale, sw->ldiag, dk, sw->dfrag, sw->dscale, la->update);
+            if (rc == 0) rc = launch_trsm_panel_h3(akk + nbk * ld, ld, m, sw->ldiag, sw->dfrag, sw->dscale, nbk, pk_rows, ldp, sw->scale, la->update);
         } else if (fused)
             rc = launch_trsm_panel_f32(akk + nbk * ld, ld, m, akk, ld, dk, nbk, planes_here ? pk_rows : nullptr, ldp,
                                        h3 ? sw->scale : 1.0f, la->update);
@@ -1461,8 +1462,8 @@ int potrf_panel_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamp
         const int64_t ldp = planes_ok ? 4 * sw->k_cap : 0;
         char* rows = planes_ok ? sw->planes + (o / w) * sw->col_stride + (o + w) * ldp : nullptr;
         if (planes_ok && o > 0 && w == 1024 && sw->ldiag != nullptr && sw->dfrag != nullptr && NNGP_KNOB(2) != 5) {
-            NNGP_TRY(launch_split_diag_frag(akk, ld, w, sw->scale, sw->ldiag, dk, sw->dfrag, s));
-            NNGP_TRY(launch_trsm_panel_h3(akk + w * ld, ld, m, sw->ldiag, sw->dfrag, w, rows, ldp, sw->scale, s));
+            NNGP_TRY(launch_split_diag_frag(akk, ld, w, sw->scale, sw->ldiag, dk, sw->dfrag, sw->dscale, s));
+            NNGP_TRY(launch_trsm_panel_h3(akk + w * ld, ld, m, sw->ldiag, sw->dfrag, sw->dscale, w, rows, ldp, sw->scale, s));
         } else {
             NNGP_TRY(launch_trsm_panel_f32(akk + w * ld, ld, m, akk, ld, dk, w, rows, ldp, planes_ok ? sw->scale : 1.0f, s));
         }

@@ -219,24 +219,43 @@ __device__ __forceinline__ int lds_off16(int row, int ch) { return row * 128 + (
 // group wc, k16 half g) one contiguous 2 KB piece = [64 lanes x 16 bytes of hi halfs | the same of lo halfs], lane = row % 32 +
 // 32 * (k8 group & 1) -- so that a wave's operand load is ONE fully coalesced kilobyte.  (Loading the same fragments from
 // row-major split rows costs 32 cache lines per instruction; measured 760-1480 cycles per 32-k step, TCP-bound.)
-// The same launch re-orders the inverted 128-blocks (float32) the same way: piece (jb, t, s, wc, g) = 64 lanes x 16 bytes, lane
-// (row % 32, fh) holding dinv_jb[32 wc + row % 32][(3 - t) 32 + 16 g + 8 s + 4 fh .. + 3] -- the operand of phase B.
+// The same launch re-orders the inverted 128-blocks the same way -- round 5: as split halves too, every ROW of an inverted block (an
+// output column of the panel solve) with its own power-of-two scale (largest entry -> [2^13, 2^14); dscale[row] = 1 / scale): piece
+// (jb, t, wc, g) = [64 lanes x 16 bytes of hi halfs | the same of lo halfs], lane (row % 32, fh) holding
+// dinv_jb[32 wc + row % 32][(3 - t) 32 + 16 g + 8 fh .. + 7] -- the operand of phase B on the float16 pipe.
 __global__ __launch_bounds__(256) void k_split_diag_frag(const float* __restrict__ a, int64_t ld, int w, float scale,
                                                          char* __restrict__ out, const float* __restrict__ dinv,
-                                                         float* __restrict__ dfrag) {
+                                                         char* __restrict__ dfrag, float* __restrict__ dscale) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int k8_per_row = w >> 3;
     const int r = idx / k8_per_row, c8 = idx - r * k8_per_row;
     if (r >= w) return;
-    if (c8 < 16) {  // the 128 x 128 inverse of this row's diagonal block: 16 groups of 8 k per row
+    if (c8 < 16) {  // the 128 x 128 inverse of this row's diagonal block: 16 groups of 8 k per row = 16 consecutive lanes of one wave
         const int jb = r >> 7, cjr = r & 127, wcr = cjr >> 5, fr = cjr & 31;
         const float* srcd = dinv + (int64_t)jb * 128 * 128 + cjr * 128 + c8 * 8;
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(srcd), d1 = *reinterpret_cast<const f32x4*>(srcd + 4);
-        // k = 8 c8 + 4 fh + e  ->  t = 3 - (k >> 5), g = (k >> 4) & 1, s = (k >> 3) & 1, fh = (k >> 2) & 1
-        const int k0 = 8 * c8, t = 3 - (k0 >> 5), g = (k0 >> 4) & 1, sx = (k0 >> 3) & 1;
-        float* piece = dfrag + ((((int64_t)jb * 4 + t) * 2 + sx) * 4 + wcr) * 2 * 256 + g * 256;  // 64 lanes x 4 floats per piece
-        *reinterpret_cast<f32x4*>(piece + fr * 4) = d0;          // fh = 0
-        *reinterpret_cast<f32x4*>(piece + (32 + fr) * 4) = d1;   // fh = 1
+        float mx = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(d0[e]), fabsf(d1[e])));
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        int e2 = 0;
+        (void)frexpf(mx, &e2);
+        const float sc = (mx > 0.0f && mx < 3.0e38f) ? ldexpf(1.0f, 14 - e2) : 1.0f;
+        if (c8 == 0) dscale[r] = 1.0f / sc;
+        h8 dhi, dlo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (e < 4 ? d0[e] : d1[e - 4]) * sc;
+            const _Float16 h = (_Float16)x;
+            dhi[e] = h;
+            dlo[e] = (_Float16)(x - (float)h);
+        }
+        // k = 8 c8 + e  ->  t = 3 - (k >> 5), g = (k >> 4) & 1, fh = (k >> 3) & 1
+        const int k0 = 8 * c8, t = 3 - (k0 >> 5), g = (k0 >> 4) & 1, fhd = (k0 >> 3) & 1;
+        char* piece = dfrag + ((((int64_t)jb * 4 + t) * 4 + wcr) * 2 + g) * 2048 + (fr + 32 * fhd) * 16;
+        *reinterpret_cast<h8*>(piece) = dhi;
+        *reinterpret_cast<h8*>(piece + 1024) = dlo;
     }
     const f32x4* src = reinterpret_cast<const f32x4*>(a + (int64_t)r * ld + c8 * 8);
     const f32x4 v0 = src[0], v1 = src[1];
@@ -257,8 +276,8 @@ __global__ __launch_bounds__(256) void k_split_diag_frag(const float* __restrict
 }
 
 __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, int64_t ldb, const char* __restrict__ lsplit,
-                                                       const float* __restrict__ dinv, int w, char* __restrict__ planes,
-                                                       int64_t ldp, float scale, TPlanes tp) {
+                                                       const char* __restrict__ dfrag, const float* __restrict__ dscale, int w,
+                                                       char* __restrict__ planes, int64_t ldp, float scale, TPlanes tp) {
     __shared__ __attribute__((aligned(16))) char Xp[PR * HXS];     // solved blocks, split rows: [row][k / 32][32 hi | 32 lo]
     __shared__ __attribute__((aligned(16))) float Tf[PR * TFS];    // current block in float32: B_j, then T, then X_j
     __shared__ __attribute__((aligned(16))) float Lf[PR * TFS];    // partial sums of wave group 1, laid out like Tf (lanes along a row:
@@ -269,6 +288,9 @@ __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, in
     const int64_t row0 = (int64_t)blockIdx.x * PR;
     float* bg = b + row0 * ldb;
     const float inv_s2 = 1.0f / (scale * scale);
+    // Phase B on the float16 pipe (round 5): T = X_j L_jj^T is bounded by max A <= (max |L|)^2, and max |L| scale < 2^15: with
+    // scale_t = scale^2 / 2^16 every entry of T scale_t stays below 2^14 -- one constant power of two, no pass over T for a scale
+    const float scale_t = scale * scale * (1.0f / 65536.0f);
     const int crow = tid >> 4, cc8 = tid & 15;  // this thread's (row, group of 8 columns) in the cooperative passes
     const int cj = 32 * wc + frow;              // this lane's output column inside a 128-column block = its row of L / dinv
     // A wave's B operand is private to it (rows 32 wc .. 32 wc + 31 of the L / dinv block, the k16 half `grp`): it is loaded
@@ -280,16 +302,20 @@ __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, in
     const int nblk = w / 128;
     // Operands of block j + 1 that do not depend on block j -- its rows of B, this wave's part of dinv_{j+1}, the first group of
     // L[j+1, :] fragments -- are requested while block j is still being finished, so that no L2 round trip sits between blocks.
-    f32x4 b0, b1, dv[4][2];
+    f32x4 b0, b1;
+    h8 dvh[4], dvl[4];                // this wave's fragments of the inverted 128-block (split halves), four k16 steps
+    float dsc = 1.0f;                 // 1 / scale of its row of that block (= this lane's output column)
     h8 nh[4], nl[4], nh2[4], nl2[4];  // L fragments one and two groups (of four 32-k blocks) ahead of the MFMAs
     auto load_block_inputs = [&](int jj) {
         b0 = *reinterpret_cast<const f32x4*>(bg + (int64_t)crow * ldb + 128 * jj + 8 * cc8);
         b1 = *reinterpret_cast<const f32x4*>(bg + (int64_t)crow * ldb + 128 * jj + 8 * cc8 + 4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx)
-                dv[t][sidx] = *reinterpret_cast<const f32x4*>(dinv + (((((int64_t)jj * 4 + t) * 2 + sidx) * 4 + wc) * 2 + grp) * 256 + lane * 4);
+        for (int t = 0; t < 4; ++t) {
+            const char* piece = dfrag + ((((int64_t)jj * 4 + t) * 4 + wc) * 2 + grp) * 2048 + lane * 16;
+            dvh[t] = *reinterpret_cast<const h8*>(piece);
+            dvl[t] = *reinterpret_cast<const h8*>(piece + 1024);
+        }
+        dsc = dscale[128 * jj + cj];
     };
     // fragments of L[jj, :] for k-blocks kb_hi .. kb_hi - 3 (k_split_diag_frag order) into (dh, dl)
     auto load_group = [&](h8 (&dh)[4], h8 (&dl)[4], int jj, int kb_hi) {
@@ -309,11 +335,10 @@ __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, in
         const unsigned long long wstart_ = __builtin_amdgcn_s_memtime();
 #endif
         const f32x4 cb0 = b0, cb1 = b1;
-        f32x4 cdv[4][2];
+        h8 cdh[4], cdl[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) cdv[t][sidx] = dv[t][sidx];
+        for (int t = 0; t < 4; ++t) { cdh[t] = dvh[t]; cdl[t] = dvl[t]; }
+        const float cds = dsc * (1.0f / scale_t);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -368,20 +393,30 @@ __global__ __launch_bounds__(512) void k_trsm_panel_h3(float* __restrict__ b, in
 #ifdef NNGP_TIMING_KNOBS
         if (blockIdx.x == 0 && lane == 0) atomicAdd(&g_trsm_wave[8 + wave], __builtin_amdgcn_s_memtime() - wstart_);
 #endif
-        // ---- phase B: X_j = T dinv_j^T in float32 (split-K over the two wave groups), dinv fragments already in registers ----
+        // ---- phase B: X_j = T dinv_j^T on the float16 pipe too (round 5; until then float32 MFMAs: 60 % of the kernel's matrix time):
+        // split-K over the two wave groups, the block's fragments already in registers; a lane's 8 consecutive k of T are split as
+        // they are read (hi + lo of T scale_t), three products per k16 step, the row scales of the inverted block come back per lane ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int k0 = (3 - t) * 32 + 16 * grp;
+            const int k0 = (3 - t) * 32 + 16 * grp + 8 * fh;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(&Tf[frow * TFS + k0]);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(&Tf[frow * TFS + k0 + 4]);
+            h8 th, tl;
 #pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                const f32x4 fa = *reinterpret_cast<const f32x4*>(&Tf[frow * TFS + k0 + (2 * sidx + fh) * 4]);
-                const f32x4 fb = cdv[t][sidx];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+            for (int e = 0; e < 8; ++e) {
+                const float x = (e < 4 ? t0[e] : t1[e - 4]) * scale_t;
+                const _Float16 h = (_Float16)x;
+                th[e] = h;
+                tl[e] = (_Float16)(x - (float)h);
             }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, cdl[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, cdh[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, cdh[t], acc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= cds;
         if (grp == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Lf[((r & 3) + 8 * (r >> 2) + 4 * fh) * TFS + cj] = acc[r];
@@ -464,30 +499,31 @@ int launch_trsm_panel_f32(float* b, int64_t ldb, int64_t m, const float* l, int6
 namespace nngp {
 // Split copy of the w x w diagonal block at `a` in the fragment order of k_trsm_panel_h3 (4 w^2 bytes at `out`).
 int launch_split_diag_frag(const float* a, int64_t ld, int64_t w, float scale, char* out, const float* dinv, float* dfrag,
-                           hipStream_t s) {
+                           float* dscale, hipStream_t s) {
     NNGP_REQUIRE(w > 0 && w % 128 == 0 && w <= PWMAX && ld % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
-                     dinv != nullptr && dfrag != nullptr && ((uintptr_t)dinv & 15) == 0 && ((uintptr_t)dfrag & 15) == 0,
+                     dinv != nullptr && dfrag != nullptr && dscale != nullptr && ((uintptr_t)dinv & 15) == 0 && ((uintptr_t)dfrag & 15) == 0,
                  "split_diag_frag: w must be a multiple of 128 up to 1024, operands 16-byte aligned");
     const int64_t total = w * (w / 8);
-    hipLaunchKernelGGL(k_split_diag_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ld, (int)w, scale, out, dinv, dfrag);
+    hipLaunchKernelGGL(k_split_diag_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ld, (int)w, scale, out, dinv,
+                       reinterpret_cast<char*>(dfrag), dscale);
     NNGP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 // b [m, w] <- b * L^-T with the left-looking products on the float16 pipe.  lfrag: launch_split_diag_frag of the diagonal block
 // (same scale) -- only its strictly lower 128-blocks are read; dfrag: the inverted 128-blocks in the order the same launch wrote them.
-int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, int64_t w, char* planes,
-                         int64_t ldp, float scale, hipStream_t s, char* planes_t, int64_t tstride, int64_t row0, int64_t col0) {
+int launch_trsm_panel_h3(float* b, int64_t ldb, int64_t m, const char* lfrag, const float* dinv, const float* dscale, int64_t w,
+                         char* planes, int64_t ldp, float scale, hipStream_t s, char* planes_t, int64_t tstride, int64_t row0, int64_t col0) {
     if (m <= 0 || w <= 0) return 0;
     NNGP_REQUIRE(m % PR == 0 && w % 128 == 0 && w <= PWMAX, "trsm_panel_h3: m must be a multiple of 32, w of 128 and <= 1024");
-    NNGP_REQUIRE(ldb % 4 == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)dinv & 15) == 0 && lfrag != nullptr &&
+    NNGP_REQUIRE(ldb % 4 == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)dinv & 15) == 0 && dscale != nullptr && lfrag != nullptr &&
                      ((uintptr_t)lfrag & 15) == 0 && ldp % 16 == 0 && ldp >= 4 * w && scale > 0.0f,
                  "trsm_panel_h3: operands must be 16-byte aligned with ldp >= 4 w");
     NNGP_REQUIRE(planes == nullptr || ((uintptr_t)planes & 15) == 0, "trsm_panel_h3: split rows must be 16-byte aligned");
     NNGP_REQUIRE(planes_t == nullptr || (row0 % 32 == 0 && col0 % 128 == 0 && tstride % 16 == 0 && ((uintptr_t)planes_t & 15) == 0),
                  "trsm_panel_h3: the transposed split copy needs rows at multiples of 32 and columns at multiples of 128");
-    hipLaunchKernelGGL(k_trsm_panel_h3, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, lfrag, dinv, (int)w, planes, ldp, scale,
-                       make_tplanes(planes_t, tstride, row0, col0));
+    hipLaunchKernelGGL(k_trsm_panel_h3, dim3((unsigned)(m / PR)), dim3(512), 0, s, b, ldb, lfrag, reinterpret_cast<const char*>(dinv), dscale,
+                       (int)w, planes, ldp, scale, make_tplanes(planes_t, tstride, row0, col0));
     NNGP_HIP_CHECK(hipGetLastError());
 #ifdef NNGP_TIMING_KNOBS
     if (NNGP_KNOB(7) == 9) {  // timing study: cycles of workgroup 0 per phase, summed over the launches so far
