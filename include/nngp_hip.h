@@ -352,12 +352,14 @@ int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode,
  * on device counters for the items they depend on (csrc/trsm_tickets.hip).  The order of the tickets is fixed on the host, and the
  * launch cannot hang if every item's dependencies hold LOWER tickets.  This entry point returns that table for a shape -- row_tiles
  * tiles of 128 rows, block_cols block columns of 1024 (the last one tail_tiles <= 8 tiles of 128 wide), forward (0) or backward (1)
- * solve, as scheduled for `workers` resident workgroups -- as four int32 per item {type | panels << 4, row tile, column tile or
+ * solve, as scheduled for `workers` resident workgroups, with (merged = 1) or without the chain updates formed straight from the
+ * previous block's split rows (type 5) -- as four int32 per item {type | panels << 4, row tile, column tile or
  * 32-row group, block column}; type 0 = split of an updated block, 1 = diagonal-product tile, 2 = split of a solved block,
  * 3 = update of one 128 x 128 tile, 4 = update of the 2 x 2 group of tiles (2 r, 2 r + 1) x (2 c, 2 c + 1) as one 256 x 256 tile
- * (an update's `panels` finished block columns start at `block column` and go back in solve order).  Host memory, no GPU
+ * (an update's `panels` finished block columns start at `block column` and go back in solve order), 5 = the last update of a
+ * tile from the split rows of the block column right before its own.  Host memory, no GPU
  * needed; items == NULL only counts.  tests/test_host.py replays the tables against the kernel's own wait conditions. */
-int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers,
+int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged,
                            int32_t* items /* host, 4 * cap */, int64_t cap, int64_t* count /* host */);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,

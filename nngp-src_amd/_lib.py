@@ -148,7 +148,7 @@ def bind_prototypes(lib, knobs: bool = False):
     lib.nngp_model_trsm_timer_read.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     lib.nngp_model_reserve.argtypes = [vp, i64, i32]
     lib.nngp_alloc_count.argtypes = []
-    lib.nngp_trsm_ticket_order.argtypes = [i32, i32, i32, i32, i32, vp, i64, ctypes.POINTER(i64)]
+    lib.nngp_trsm_ticket_order.argtypes = [i32, i32, i32, i32, i32, i32, vp, i64, ctypes.POINTER(i64)]
     lib.nngp_model_factor_update_cols.argtypes = [vp, i64, i64, ctypes.POINTER(i64), i32, i64, vp]
     for name in ABI_SYMBOLS:
         if name not in ("nngp_last_error", "nngp_model_factor_shift", "nngp_comm_library", "nngp_alloc_count"):

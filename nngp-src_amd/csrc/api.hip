@@ -608,7 +608,7 @@ int tri_join(nngp_model* m, hipStream_t s) {
     if (m->tri_stale) {
         if (m->ev_tri == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri, hipEventDisableTiming));
         NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, s));
-        if (m->tk != nullptr && m->tri.bs == 1024) NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, s));
+        if (m->tk != nullptr && m->tri.bs == 1024) NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, m->a32, m->ld, s));
         NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, s));
         m->tri_stale = false;
         m->tri_pending = true;
@@ -616,7 +616,7 @@ int tri_join(nngp_model* m, hipStream_t s) {
     }
     if (m->tri_pending) NNGP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_tri, 0));
     if (m->tk != nullptr && !tk_inverses_ready(m->tk) && m->tri.bs == 1024) {  // the workspace was rebuilt after the blocks were inverted
-        NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, s));
+        NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, m->a32, m->ld, s));
         if (m->ev_tri == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_tri, hipEventDisableTiming));
         NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, s));
         m->tri_pending = true;
@@ -632,7 +632,7 @@ int tri_fork(nngp_model* m, hipStream_t s) {
     NNGP_HIP_CHECK(hipEventRecord(m->ev_tri_fork, s));
     NNGP_HIP_CHECK(hipStreamWaitEvent(m->la->panel, m->ev_tri_fork, 0));
     NNGP_TRY(triinv_build(m->a32, m->ld, m->dinv, m->np, m->tri, m->la->panel));
-    if (m->tk != nullptr && m->tri.bs == 1024) NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, m->la->panel));
+    if (m->tk != nullptr && m->tri.bs == 1024) NNGP_TRY(tk_prepare_inverses(m->tk, m->tri, m->np, m->a32, m->ld, m->la->panel));
     NNGP_HIP_CHECK(hipEventRecord(m->ev_tri, m->la->panel));
     m->tri_stale = false;
     m->tri_pending = true;
@@ -2040,9 +2040,9 @@ int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode,
     return 0;
 }
 
-int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t* items,
-                           int64_t cap, int64_t* count) {
-    return tk_order_export(row_tiles, block_cols, tail_tiles, backward, workers, items, cap, count);
+int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged,
+                           int32_t* items, int64_t cap, int64_t* count) {
+    return tk_order_export(row_tiles, block_cols, tail_tiles, backward, workers, merged, items, cap, count);
 }
 
 int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream) {

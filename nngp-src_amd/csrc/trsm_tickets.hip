@@ -8,6 +8,9 @@
 //   D (r, c)     X[r, c] = sum_k B_J[r, k] Linv_J[c, k]      128 x 128 tile of the diagonal product, K <= 1024, triangular
 //   SX(r, J, q)  split copy of 16 rows of X_J[r]
 //   U (r, c, P)  B[r, c] -= sum_{J in P} X_J[r] L[c, J]^T     128 x 128 tile, K = 1024 |P|, up to four finished block columns per pass
+//   UB            the same for a 2 x 2 group of tiles as one 256 x 256 tile (the bulk of the flops)
+//   UW(r, c, J)  B[r, c] -= B_J[r] W_J[c]^T, W_J = L[next block, J] Linv_J: the LAST update of the next block column straight from the
+//                split rows of B_J -- X_J = B_J Linv_J^T and its split leave the dependency chain (they still feed the other updates)
 //
 // r = tile of 128 right-hand-side rows, c = tile of 128 columns, J = block column of 1024.  Different r never interact, so the
 // dependencies are four monotone counters per r (device memory, zeroed before the launch): updates applied to tile (r, c),
@@ -53,7 +56,7 @@ constexpr int64_t kLdp = 4096;           // bytes per split row (1024 k x 4 byte
 constexpr int kBs = 1024;                // block-column width
 constexpr int kQ = 4;                    // split items per (r, J): 32 rows each (8 waves x 4 rows)
 
-enum { IT_SB = 0, IT_D = 1, IT_SX = 2, IT_U = 3, IT_UB = 4 };
+enum { IT_SB = 0, IT_D = 1, IT_SX = 2, IT_U = 3, IT_UB = 4, IT_UW = 5 };
 enum { SY_TICKET = 0, SY_ERROR = 1, SY_COUNTERS = 16 };
 
 struct TkParams {
@@ -63,6 +66,8 @@ struct TkParams {
     int64_t l_stride;         // bytes between block columns
     const char* dinv_s;       // split copies of the inverted diagonal blocks, [nb][1024 rows][4096 bytes]
     const float* dinv_iscale; // [nb] 1 / scale of each
+    const char* wplanes;      // split copies of the merged chain operands W_J (IT_UW), [nb][1024 rows][4096 bytes]
+    const float* w_iscale;    // [nb] 1 / scale of each
     char* planes_x;           // [nb][m_cap][4096]
     char* planes_d;
     int64_t p_stride;         // bytes between block columns of planes_x / planes_d
@@ -98,8 +103,8 @@ __device__ __forceinline__ void st4_wt(float* p, float v) {
 
 #ifdef NNGP_TIMING_KNOBS
 // timing study (knobs build): s_memrealtime ticks (10 ns) summed over all workgroups, per item type t = 0..3:
-// [t*4 + 0] wait + acquire, [t*4 + 1] body, [t*4 + 2] publish + next ticket, [t*4 + 3] items (t = 0..4); [20] kernel ticks summed, [21] workgroups
-__device__ unsigned long long g_tk_stamps[24];
+// [t*4 + 0] wait + acquire, [t*4 + 1] body, [t*4 + 2] publish + next ticket, [t*4 + 3] items (t = 0..5); [24] kernel ticks summed, [25] workgroups
+__device__ unsigned long long g_tk_stamps[28];
 #define TK_NOW() __builtin_amdgcn_s_memrealtime()
 #else
 #define TK_NOW() 0ULL
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
     int ticket = __builtin_amdgcn_readfirstlane(s_word);
     __syncthreads();
 #ifdef NNGP_TIMING_KNOBS
-    unsigned long long st[20] = {};
+    unsigned long long st[24] = {};
     const unsigned long long st_k0 = TK_NOW();
 #endif
     while (ticket < P.n_items) {
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
         const int r = __builtin_amdgcn_readfirstlane(it.y), cq = __builtin_amdgcn_readfirstlane(it.z),
                   J = __builtin_amdgcn_readfirstlane(it.w);
         // r, cq: tile of 128 rows / columns (IT_UB: tile of 256 = tiles 2 r, 2 r + 1 / 2 cq, 2 cq + 1; split items: cq = row group)
-        const int Jc = type == IT_UB ? cq / 4 : (type == IT_U || type == IT_D) ? cq / 8 : J;  // block column of the target
+        const int Jc = type == IT_UB ? cq / 4 : (type == IT_U || type == IT_D || type == IT_UW) ? cq / 8 : J;  // block column of the target
         const int ct_j = (Jc == nb - 1) ? P.tail_ct : 8;
 
         // ---- dependencies: wave 0 polls, one counter per lane ----
@@ -173,6 +178,9 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
             const int need_up = P.backward ? nb - 1 - first_in_time : first_in_time;
             if (type == IT_U) {
                 if (lane == 0) { addr = cnt_xs + r * nb + J; need = kQ; active = true; }
+                if (lane == 1) { addr = cnt_up + r * P.ctiles + cq; need = need_up; active = true; }
+            } else if (type == IT_UW) {  // the split rows of B_J instead of those of X_J
+                if (lane == 0) { addr = cnt_bs + r * nb + J; need = kQ; active = true; }
                 if (lane == 1) { addr = cnt_up + r * P.ctiles + cq; need = need_up; active = true; }
             } else if (type == IT_UB) {
                 if (lane < 2) { addr = cnt_xs + (2 * r + lane) * nb + J; need = kQ; active = true; }
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
             done_stride2 = P.ctiles;
         } else {
             // ---- 128 x 128 tile item (diagonal product, or an update on the chain) on waves 0-3; waves 4-7 keep the barriers ----
-            const bool is_u = type == IT_U;
+            const bool is_w = type == IT_UW;
+            const bool is_u = type == IT_U || is_w;
             const int cl = cq - Jc * 8;  // tile inside its block column
             // operands: k-blocks kb_hi down to kb_lo of every panel; panel p lies a_pst / b_pst bytes from panel p - 1
             int kb_lo, kb_hi;
@@ -456,8 +465,9 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
                 const int ct_p = (J == nb - 1) ? P.tail_ct : 8;  // (a tail panel is never grouped with others)
                 kb_lo = 0;
                 kb_hi = ct_p * 4 - 1;
-                pa = P.planes_x + (int64_t)J * P.p_stride + (int64_t)(r * TT) * kLdp;
-                pb = P.lplanes + (int64_t)J * P.l_stride + (int64_t)(cq * TT) * kLdp;
+                pa = (is_w ? P.planes_d : P.planes_x) + (int64_t)J * P.p_stride + (int64_t)(r * TT) * kLdp;
+                pb = is_w ? P.wplanes + (int64_t)J * ((int64_t)kBs * kLdp) + (int64_t)(cl * TT) * kLdp
+                          : P.lplanes + (int64_t)J * P.l_stride + (int64_t)(cq * TT) * kLdp;
                 a_pst = P.backward ? P.p_stride : -P.p_stride;
                 b_pst = P.backward ? P.l_stride : -P.l_stride;
             } else {
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
                         if (p < npan) {
-                            const float* rv = P.rinv_x + (int64_t)(P.backward ? J + p : J - p) * P.r_stride + row_base + r16;
+                            const float* rv = (is_w ? P.rinv_d : P.rinv_x) + (int64_t)(P.backward ? J + p : J - p) * P.r_stride + row_base + r16;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) rs[p][i] = rv[16 * i];
                         }
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float last = pcur == 0 ? rs[0][i] : pcur == 1 ? rs[1][i] : pcur == 2 ? rs[2][i] : rs[3][i];
-                    fs[i] = last * (is_u ? -P.l_iscale : P.dinv_iscale[Jc]);
+                    fs[i] = last * (is_w ? -P.w_iscale[J] : is_u ? -P.l_iscale : P.dinv_iscale[Jc]);
                 }
                 const unsigned voff = ((unsigned)r16 * (unsigned)P.ldb + 4u * (unsigned)q4) * 4u;
                 char* cw = reinterpret_cast<char*>(P.b + (int64_t)(row_base)*P.ldb + (int64_t)cq * TT + wn * 64);
@@ -657,9 +667,9 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
     }
 #ifdef NNGP_TIMING_KNOBS
     if (tid == 0) {
-        for (int i = 0; i < 20; ++i) atomicAdd(&g_tk_stamps[i], st[i]);
-        atomicAdd(&g_tk_stamps[20], TK_NOW() - st_k0);
-        atomicAdd(&g_tk_stamps[21], 1ULL);
+        for (int i = 0; i < 24; ++i) atomicAdd(&g_tk_stamps[i], st[i]);
+        atomicAdd(&g_tk_stamps[24], TK_NOW() - st_k0);
+        atomicAdd(&g_tk_stamps[25], 1ULL);
     }
 #endif
 }
@@ -707,16 +717,36 @@ __global__ __launch_bounds__(256) void k_split_blocks(const float* __restrict__ 
     *reinterpret_cast<h8*>(dst + 64) = lo;
 }
 
+// dst_b [c][n] = src_b [n][c] for 1024 x 1024 blocks b: src_b = src + b * sstride (row stride lds), dst_b = dst + b * 1024 * 1024
+__global__ __launch_bounds__(256) void k_transpose_1024(const float* __restrict__ src, int64_t lds, int64_t sstride, float* __restrict__ dst, int rows_valid_last, int nblk) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const float* sp = src + (int64_t)b * sstride;
+    float* dp = dst + (int64_t)b * kBs * kBs;
+    const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;   // source rows n, source columns c
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int nvalid = (b == nblk - 1) ? rows_valid_last : kBs;  // the last block may have fewer source rows (tail of the factor)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i;
+        tile[ty + 8 * i][tx] = n < nvalid ? sp[(int64_t)n * lds + c0 + tx] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dp[(int64_t)(c0 + ty + 8 * i) * kBs + n0 + tx] = tile[tx][ty + 8 * i];
+}
+
 // ---- host: the ticket order ----
 // List scheduling on `workers` simulated workgroups with rough item durations: an item enters the table when the simulation starts
 // it, i.e. after everything it depends on has FINISHED there -- so every dependency has a lower ticket whatever the real timing is.
 // Priority: earliest deadline first, the deadline of an item being the block column it feeds (diagonal chain items before the
 // updates of the next block column).  Updates come in two shapes: a 2 x 2 group of tiles takes every finished block column that is
-// waiting for it EXCEPT the one right before its own block, up to four at a time, as one 256 x 256 item (deep K where the chip is
-// throughput-bound); the last block column before a tile's own -- the update on the dependency chain -- is applied tile by tile
-// (128 x 128 items: four times the parallelism where only latency counts).  Tiles without a partner (odd row-tile count, odd tail)
+// waiting for it EXCEPT the two right before its own block, up to four at a time, as one 256 x 256 item (deep K where the chip is
+// throughput-bound); the last two block columns before a tile's own -- the updates on or next to the dependency chain -- are applied
+// tile by tile (128 x 128 items: four times the parallelism where only latency counts).  Tiles without a partner (odd row-tile count, odd tail)
 // take all their updates as 128 x 128 items.
-void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std::vector<int4>& out) {
+// merged: the chain update of a paired tile is a UW item (it waits for the split rows of the previous block B_J, not for X_J)
+void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, bool merged, std::vector<int4>& out) {
     const int ctiles = (nb - 1) * 8 + tail_ct;
     auto ct_of = [&](int J) { return J == nb - 1 ? tail_ct : 8; };
     auto pos_of = [&](int J) { return backward ? nb - 1 - J : J; };  // position of block column J in solve order (0 = solved first)
@@ -746,6 +776,7 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
     std::vector<char> busy((size_t)mt * ctiles, 0);   // an update of the tile is queued or running
     std::vector<int> xs((size_t)mt * nb, 0), xd((size_t)mt * nb, 0), bs((size_t)mt * nb, 0), tiles_final((size_t)mt * nb, 0);
     std::vector<int> xready((size_t)mt, 0);           // positions [0, xready[r]) have their split X
+    std::vector<int> bready((size_t)mt, 0);           // positions [0, bready[r]) have their split B (the merged chain update's operand)
     const int mt2 = mt / 2, ct2 = ctiles / 2;         // 2 x 2 groups: row tiles (2 r2, 2 r2 + 1), column tiles (2 c2, 2 c2 + 1) -- same block (8 | 2 c2)
     auto paired = [&](int r, int c) { return !no_big && r < 2 * mt2 && c < 2 * ct2 && (c / 8 != nb - 1 || (c % 8) + (c % 2 == 0 ? 1 : 0) < ct_of(nb - 1)); };
     auto tile_id = [&](int r, int c) { return (size_t)r * ctiles + c; };
@@ -753,7 +784,16 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
     auto queue_final = [&](int r, int c) {
         const size_t id = tile_id(r, c);
         const int pc = pos_of(c / 8);
-        if (busy[id] || pc == 0 || up[id] != pc - 1 || xready[r] < pc) return;
+        if (busy[id] || pc == 0 || up[id] != pc - 1 || (merged ? bready[r] : xready[r]) < pc) return;
+        busy[id] = 1;
+        ready.push(Ready{2 * pc - 1, c, r, merged ? IT_UW : IT_U, 0, K_TILE});
+    };
+    // the update before that (two block columns back): a 128 x 128 item as well -- as part of a 256 x 256 item (~100 us) it would sit
+    // between X_J and the chain update of the block after next, i.e. on the chain
+    auto queue_near = [&](int r, int c) {
+        const size_t id = tile_id(r, c);
+        const int pc = pos_of(c / 8);
+        if (busy[id] || pc < 2 || up[id] != pc - 2 || xready[r] < pc - 1) return;
         busy[id] = 1;
         ready.push(Ready{2 * pc - 1, c, r, IT_U, 0, K_TILE});
     };
@@ -774,7 +814,7 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
             for (int dc = 0; dc < 2; ++dc)
                 if (busy[tile_id(r + dr, c + dc)] || up[tile_id(r + dr, c + dc)] != p0) return;
         const int xr = std::min(xready[r], xready[r + 1]);
-        if (std::min(pc - 1, xr) - p0 < 1) return;
+        if (std::min(pc - 2, xr) - p0 < 1) return;
         for (int dr = 0; dr < 2; ++dr)
             for (int dc = 0; dc < 2; ++dc) busy[tile_id(r + dr, c + dc)] = 1;
         ready.push(Ready{2 * pc - 1, c, r, IT_UB, 0, K_PAIR});
@@ -782,6 +822,7 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
     auto requeue_tile = [&](int r, int c) {
         if (paired(r, c)) {
             queue_pair(r / 2, c / 2);
+            queue_near(r, c);
             queue_final(r, c);
         } else {
             queue_single(r, c);
@@ -804,13 +845,18 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
             if (it.type == IT_UB) {
                 const int r = it.r, c = it.c, pc = pos_of(c / 8);
                 const int p0 = up[tile_id(r, c)];
-                int avail = std::min(pc - 1, std::min(xready[r], xready[r + 1])) - p0;
+                int avail = std::min(pc - 2, std::min(xready[r], xready[r + 1])) - p0;
                 if (avail > max_pan) avail = max_pan;
                 if (backward && tail_ct != 8 && p0 == 0) avail = 1;  // a tail-width block column goes alone
                 const int plast = p0 + avail - 1;                    // latest block column of the item in solve order = first processed
                 rec = int4{IT_UB | (avail << 4), r / 2, c / 2, blk_at(plast)};
                 const int nk = (backward && tail_ct != 8 && p0 == 0) ? tail_ct * 4 : 32;
                 d = Done{now + t_big0 + t_bigstage * nk * avail, IT_UB, r, c, 0, avail};
+            } else if (it.type == IT_UW) {
+                const int pc = pos_of(it.c / 8);
+                const int Jsrc = blk_at(pc - 1);
+                rec = int4{IT_UW | (1 << 4), it.r, it.c, Jsrc};
+                d = Done{now + t_tile0 + t_stage * 4 * ct_of(Jsrc), IT_UW, it.r, it.c, 0, 1};
             } else if (it.type == IT_U) {
                 const size_t id = tile_id(it.r, it.c);
                 const int pc = pos_of(it.c / 8);
@@ -818,6 +864,7 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
                 int avail = std::min(pc, xready[it.r]) - p0;
                 if (avail > max_pan) avail = max_pan;
                 if (backward && tail_ct != 8 && p0 == 0) avail = 1;
+                if (paired(it.r, it.c)) avail = 1;  // the near or the chain update of a paired tile: one block column
                 const int plast = p0 + avail - 1;
                 rec = int4{IT_U | (avail << 4), it.r, it.c, blk_at(plast)};
                 const int nk = (backward && tail_ct != 8 && p0 == 0) ? tail_ct * 4 : 32;
@@ -843,7 +890,15 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, std
         ++free_workers;
         const int r = d.r;
         if (d.type == IT_SB) {
-            if (++bs[(size_t)r * nb + d.J] == kQ) push_block_items(IT_D, r, d.J);
+            if (++bs[(size_t)r * nb + d.J] == kQ) {
+                push_block_items(IT_D, r, d.J);
+                bready[r] = pos_of(d.J) + 1;
+                if (merged && pos_of(d.J) + 1 < nb) {
+                    const int Jn = blk_at(pos_of(d.J) + 1);
+                    for (int c = Jn * 8; c < Jn * 8 + ct_of(Jn); ++c)
+                        if (paired(r, c)) queue_final(r, c);
+                }
+            }
         } else if (d.type == IT_D) {
             if (++xd[(size_t)r * nb + d.J] == ct_of(d.J)) push_block_items(IT_SX, r, d.J);
         } else if (d.type == IT_SX) {
@@ -884,6 +939,14 @@ struct TrsmTickets {
     char* xinv_s = nullptr;
     char* tinv_s = nullptr;
     float* inv_iscale = nullptr;  // [2][nb_cap]: forward blocks, backward blocks
+    // merged chain operands (IT_UW): W_J = L[next block, J] Linv_J (forward), L[J, previous block]^T L_JJ^-T (backward), float32 scratch + split copies
+    float* wtmp = nullptr;        // [nb_cap][1024 x 1024]
+    float* ltb = nullptr;         // [nb_cap][1024 x 1024] transposed sub-diagonal blocks of L (backward operands)
+    char* wplanes[2] = {nullptr, nullptr};
+    float* w_iscale = nullptr;    // [2][nb_cap]
+    unsigned* wmax = nullptr;     // [2][nb_cap]
+    bool w_ready[2] = {false, false};
+    int key_merged[2] = {-1, -1};
     unsigned* amax = nullptr;     // [2][nb_cap]
     int* sync = nullptr;
     int64_t sync_ints = 0;
@@ -906,6 +969,8 @@ void tk_destroy(TrsmTickets* tk) {
     (void)hipFree(tk->planes_x); (void)hipFree(tk->planes_d); (void)hipFree(tk->rinv_x); (void)hipFree(tk->rinv_d);
     (void)hipFree(tk->xinv_s); (void)hipFree(tk->tinv_s); (void)hipFree(tk->inv_iscale); (void)hipFree(tk->amax);
     (void)hipFree(tk->sync); (void)hipFree(tk->items[0]); (void)hipFree(tk->items[1]);
+    (void)hipFree(tk->wtmp); (void)hipFree(tk->ltb); (void)hipFree(tk->wplanes[0]); (void)hipFree(tk->wplanes[1]); (void)hipFree(tk->w_iscale);
+    (void)hipFree(tk->wmax);
     if (tk->host_err) (void)hipHostFree(tk->host_err);
     if (tk->ev_err) (void)hipEventDestroy(tk->ev_err);
     delete tk;
@@ -937,6 +1002,12 @@ int tk_create(TrsmTickets** out, int64_t np_cap, int64_t m_cap) {
     A((void**)&tk->sync, sizeof(int) * tk->sync_ints);
     A((void**)&tk->items[0], sizeof(int4) * tk->items_cap);
     A((void**)&tk->items[1], sizeof(int4) * tk->items_cap);
+    A((void**)&tk->wtmp, sizeof(float) * nb * kBs * kBs);
+    A((void**)&tk->ltb, sizeof(float) * nb * kBs * kBs);
+    A((void**)&tk->wplanes[0], (size_t)nb * kBs * kLdp);
+    A((void**)&tk->wplanes[1], (size_t)nb * kBs * kLdp);
+    A((void**)&tk->w_iscale, sizeof(float) * 2 * nb);
+    A((void**)&tk->wmax, sizeof(unsigned) * 2 * nb);
     if (ok && hipHostMalloc(reinterpret_cast<void**>(&tk->host_err), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&tk->ev_err, hipEventDisableTiming) != hipSuccess) ok = false;
     if (!ok) {
@@ -957,10 +1028,14 @@ int tk_create(TrsmTickets** out, int64_t np_cap, int64_t m_cap) {
     return 0;
 }
 
-// split copies of the inverted diagonal blocks (after triinv_build, on the same stream)
-int tk_prepare_inverses(TrsmTickets* tk, const TriInv& ti, int64_t np, hipStream_t s) {
+// split copies of the inverted diagonal blocks (after triinv_build, on the same stream) and the merged chain operands
+//   forward   W_J [c, k] = sum_n L[(J+1) 1024 + c, J 1024 + n] Linv_J[n, k]      (J = 0 .. nb - 2; rows c of the next block)
+//   backward  W_J [c, k] = sum_n L[J 1024 + n, (J-1) 1024 + c] Linv_J[k, n]      (J = nb - 1 .. 1; rows c = columns of the previous block)
+// as batched float32 products with the triangular inverted blocks (l: the float32 factor, row stride ld), then split like them.
+int tk_prepare_inverses(TrsmTickets* tk, const TriInv& ti, int64_t np, const float* l, int64_t ld, hipStream_t s) {
     NNGP_REQUIRE(tk != nullptr && ti.bs == kBs && np <= tk->np_cap, "tk_prepare_inverses: bad arguments");
     const int nb = (int)((np + kBs - 1) / kBs);
+    const int tail = (int)(np - (int64_t)(nb - 1) * kBs);  // width of the last block column
     NNGP_HIP_CHECK(hipMemsetAsync(tk->amax, 0, sizeof(unsigned) * 2 * tk->nb_cap, s));
     const dim3 g1(64, (unsigned)nb), g2((unsigned)((int64_t)kBs * (kBs / 8) / 256), (unsigned)nb);
     hipLaunchKernelGGL(k_block_absmax, g1, dim3(256), 0, s, ti.xinv, (int64_t)kBs * kBs, tk->amax);
@@ -969,15 +1044,61 @@ int tk_prepare_inverses(TrsmTickets* tk, const TriInv& ti, int64_t np, hipStream
     hipLaunchKernelGGL(k_split_blocks, g2, dim3(256), 0, s, ti.tinv, kBs, tk->amax + tk->nb_cap, tk->tinv_s, tk->inv_iscale + tk->nb_cap);
     NNGP_HIP_CHECK(hipGetLastError());
     tk->inv_ready = true;
+    tk->w_ready[0] = tk->w_ready[1] = false;
+    // The merged chain updates (and the 128 x 128 near updates that go with them) pay where a solve is bound by its dependency chain,
+    // not by the operand traffic of its bulk: measured per predict of three solves after a fit, merged against plain, solves / step in ms --
+    // N = 8192, M = 1024: 1.96 / 2.37 (step equal: the operands cost the fit 0.3 ms); N = 16384 NTK: 9.1 / 10.8, step -0.8; N = 32768: 13.6 /
+    // 14.0 but step +0.7 (1 ms of operands per fit); N = 65536: 49.1 / 46.0; N = 10800, M = 3600: step +0.6.  Hence: row tiles x block columns.
+    static const char* merge_env = getenv("NNGP_TK_MERGE");  // (development aid: 0 never, 1 always)
+    const bool want = merge_env != nullptr ? atoi(merge_env) != 0 : (tk->m_cap / TT) * (int64_t)nb <= 192;
+    if (l == nullptr || nb < 2 || !want) return 0;
+    const int64_t blk = (int64_t)kBs * kBs;
+    NNGP_HIP_CHECK(hipMemsetAsync(tk->wmax, 0, sizeof(unsigned) * 2 * tk->nb_cap, s));
+    // ---- forward: W_J = L[J+1 block rows, J block columns] T_J^T with T_J = L_JJ^-T (upper): batch over J, the last target block may be a tail
+    {
+        const int full = (tail == kBs) ? nb - 1 : nb - 2;  // products whose target block has 1024 rows
+        if (full > 0)
+            NNGP_TRY(launch_gemm_nt_f32_batched(tk->wtmp, kBs, l + (int64_t)kBs * ld, ld, ti.tinv, kBs, kBs, kBs, kBs, 1.0f, 0.0f, false, full, blk,
+                                                (int64_t)kBs * ld + kBs, blk, s, 2));
+        if (full < nb - 1) {  // J = nb - 2 onto the tail block: `tail` rows; the rest of its W block is cleared (never read, but split)
+            NNGP_HIP_CHECK(hipMemsetAsync(tk->wtmp + (int64_t)(nb - 2) * blk, 0, sizeof(float) * blk, s));
+            NNGP_TRY(launch_gemm_nt_f32(tk->wtmp + (int64_t)(nb - 2) * blk, kBs, l + (int64_t)(nb - 1) * kBs * ld + (int64_t)(nb - 2) * kBs, ld,
+                                        ti.tinv + (int64_t)(nb - 2) * blk, kBs, tail, kBs, kBs, 1.0f, 0.0f, false, s, 2));
+        }
+        const dim3 gw1(64, (unsigned)(nb - 1)), gw2((unsigned)((int64_t)kBs * (kBs / 8) / 256), (unsigned)(nb - 1));
+        hipLaunchKernelGGL(k_block_absmax, gw1, dim3(256), 0, s, tk->wtmp, blk, tk->wmax);
+        hipLaunchKernelGGL(k_split_blocks, gw2, dim3(256), 0, s, tk->wtmp, kBs, tk->wmax, tk->wplanes[0], tk->w_iscale);
+        NNGP_HIP_CHECK(hipGetLastError());
+        tk->w_ready[0] = true;
+    }
+    // ---- backward: W_J = (L[J block rows, J-1 block columns])^T X_J^T with X_J = L_JJ^-1 (lower): transposed blocks first (index J - 1)
+    {
+        hipLaunchKernelGGL(k_transpose_1024, dim3(32, 32, (unsigned)(nb - 1)), dim3(256), 0, s, l + (int64_t)kBs * ld, ld, (int64_t)kBs * ld + kBs, tk->ltb, tail,
+                           nb - 1);
+        const int full = (tail == kBs) ? nb - 1 : nb - 2;  // J = 1 .. full with a 1024-wide source block
+        if (full > 0)
+            NNGP_TRY(launch_gemm_nt_f32_batched(tk->wtmp + blk, kBs, tk->ltb, kBs, ti.xinv + blk, kBs, kBs, kBs, kBs, 1.0f, 0.0f, false, full, blk, blk, blk, s, 1));
+        if (full < nb - 1) {  // J = nb - 1: a source block of `tail` rows -- K = tail, `tail` columns of W
+            NNGP_HIP_CHECK(hipMemsetAsync(tk->wtmp + (int64_t)(nb - 1) * blk, 0, sizeof(float) * blk, s));
+            NNGP_TRY(launch_gemm_nt_f32(tk->wtmp + (int64_t)(nb - 1) * blk, kBs, tk->ltb + (int64_t)(nb - 2) * blk, kBs, ti.xinv + (int64_t)(nb - 1) * blk, kBs,
+                                        kBs, tail, tail, 1.0f, 0.0f, false, s, 1));
+        }
+        const dim3 gw1(64, (unsigned)(nb - 1)), gw2((unsigned)((int64_t)kBs * (kBs / 8) / 256), (unsigned)(nb - 1));
+        hipLaunchKernelGGL(k_block_absmax, gw1, dim3(256), 0, s, tk->wtmp + blk, blk, tk->wmax + tk->nb_cap + 1);
+        hipLaunchKernelGGL(k_split_blocks, gw2, dim3(256), 0, s, tk->wtmp + blk, kBs, tk->wmax + tk->nb_cap + 1, tk->wplanes[1] + (int64_t)kBs * kLdp,
+                           tk->w_iscale + tk->nb_cap + 1);
+        NNGP_HIP_CHECK(hipGetLastError());
+        tk->w_ready[1] = true;
+    }
     return 0;
 }
 
 // the ticket table of a shape, four ints per item {type | panels << 4, r, c or q, J}, for the host-side proof that every item's
 // dependencies hold lower tickets (tests/test_host.py)
-int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int32_t* out, int64_t cap, int64_t* count) {
+int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int merged, int32_t* out, int64_t cap, int64_t* count) {
     NNGP_REQUIRE(mt >= 1 && nb >= 1 && tail_ct >= 1 && tail_ct <= 8 && workers >= 1 && count != nullptr, "trsm_ticket_order: bad shape");
     std::vector<int4> items;
-    tk_build_order(mt, nb, tail_ct, backward != 0, workers, items);
+    tk_build_order(mt, nb, tail_ct, backward != 0, workers, merged != 0, items);
     *count = (int64_t)items.size();
     if (out != nullptr) {
         NNGP_REQUIRE((int64_t)items.size() <= cap, "trsm_ticket_order: %lld items, room for %lld", (long long)items.size(), (long long)cap);
@@ -1003,11 +1124,12 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     NNGP_REQUIRE(ldb % 32 == 0 && ldb < (1LL << 26) && ((uintptr_t)b & 127) == 0, "tk_solve: right-hand sides must be 128-byte aligned rows");
     const int mt = (int)(m / TT), nb = (int)((np + kBs - 1) / kBs);
     const int tail_ct = (int)((np - (int64_t)(nb - 1) * kBs) / TT);
-    if (tk->key_mt != mt || tk->key_nb != nb || tk->key_tail != tail_ct) {
+    if (tk->key_mt != mt || tk->key_nb != nb || tk->key_tail != tail_ct || tk->key_merged[0] != (int)tk->w_ready[0] || tk->key_merged[1] != (int)tk->w_ready[1]) {
         // a new shape (the first solve, or another batch size): the device may still read the old tables
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         for (int dir = 0; dir < 2; ++dir) {
-            tk_build_order(mt, nb, tail_ct, dir == 1, tk->workers, tk->host_items[dir]);
+            tk_build_order(mt, nb, tail_ct, dir == 1, tk->workers, tk->w_ready[dir], tk->host_items[dir]);
+            tk->key_merged[dir] = (int)tk->w_ready[dir];
             NNGP_REQUIRE((int64_t)tk->host_items[dir].size() <= tk->items_cap, "tk_solve: item table overflow");
             tk->n_items[dir] = (int)tk->host_items[dir].size();
             NNGP_HIP_CHECK(hipMemcpy(tk->items[dir], tk->host_items[dir].data(), sizeof(int4) * tk->host_items[dir].size(), hipMemcpyHostToDevice));
@@ -1021,6 +1143,8 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     P.l_stride = sw.col_stride;
     P.dinv_s = backward ? tk->tinv_s : tk->xinv_s;
     P.dinv_iscale = tk->inv_iscale + (backward ? tk->nb_cap : 0);
+    P.wplanes = tk->wplanes[backward ? 1 : 0];
+    P.w_iscale = tk->w_iscale + (backward ? tk->nb_cap : 0);
     P.planes_x = tk->planes_x; P.planes_d = tk->planes_d;
     P.p_stride = tk->m_cap * kLdp;
     P.rinv_x = tk->rinv_x; P.rinv_d = tk->rinv_d;
@@ -1049,17 +1173,17 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     tk->err_pending = true;
 #ifdef NNGP_TIMING_KNOBS
     if (getenv("NNGP_TK_STAMPS") != nullptr) {
-        unsigned long long h[24];
+        unsigned long long h[28];
         (void)hipDeviceSynchronize();
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tk_stamps), sizeof(h)) == hipSuccess) {
-            static const char* names[5] = {"SB", "D", "SX", "U", "UB"};
-            fprintf(stderr, "tk stamps (%s, mt %d nb %d): %llu workgroups, mean kernel time per workgroup %.1f us\n", backward ? "backward" : "forward", mt, nb, h[21],
-                    h[21] ? 0.01 * (double)h[20] / (double)h[21] : 0.0);
-            for (int t = 0; t < 5; ++t)
+            static const char* names[6] = {"SB", "D", "SX", "U", "UB", "UW"};
+            fprintf(stderr, "tk stamps (%s, mt %d nb %d): %llu workgroups, mean kernel time per workgroup %.1f us\n", backward ? "backward" : "forward", mt, nb, h[25],
+                    h[25] ? 0.01 * (double)h[24] / (double)h[25] : 0.0);
+            for (int t = 0; t < 6; ++t)
                 fprintf(stderr, "   %-2s items %6llu: wait %.2f us  body %.2f us  publish %.2f us per item; share of workgroup time: wait %.1f %% body %.1f %% publish %.1f %%\n", names[t],
                         h[t * 4 + 3], h[t * 4 + 3] ? 0.01 * h[t * 4] / h[t * 4 + 3] : 0.0, h[t * 4 + 3] ? 0.01 * h[t * 4 + 1] / h[t * 4 + 3] : 0.0,
-                        h[t * 4 + 3] ? 0.01 * h[t * 4 + 2] / h[t * 4 + 3] : 0.0, 100.0 * h[t * 4] / (double)h[20], 100.0 * h[t * 4 + 1] / (double)h[20], 100.0 * h[t * 4 + 2] / (double)h[20]);
-            unsigned long long z[24] = {};
+                        h[t * 4 + 3] ? 0.01 * h[t * 4 + 2] / h[t * 4 + 3] : 0.0, 100.0 * h[t * 4] / (double)h[24], 100.0 * h[t * 4 + 1] / (double)h[24], 100.0 * h[t * 4 + 2] / (double)h[24]);
+            unsigned long long z[28] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tk_stamps), z, sizeof(z));
         }
     }

@@ -563,7 +563,9 @@ def test_later_residuals_with_five_rounded_planes_against_seven_and_float64(get)
     assert out[50][1] == 0 and out[0][1] >= 2 and out[0][1] == out[64][1]      # float64 pipe: no int8 launches
     assert out[0][2] < out[64][2] <= 28.0                                      # fewer plane products per launch on average
     for key in (64, 50):
-        assert np.max(np.abs(out[0][0] - out[key][0]) / np.abs(out[key][0])) < 5e-9, key
+        # (2e-8: rounding z to 40 bits below its row maximum moves a variance by what the sweeps amplify it to -- 3e-9 with round 4's
+        # step-by-step solves, 7.5e-9 with round 5's merged chain updates, whose z0 differs in its last bits; variances are gated at 1e-5)
+        assert np.max(np.abs(out[0][0] - out[key][0]) / np.abs(out[key][0])) < 2e-8, key
 
 
 def test_int8_residual_path_against_the_float64_residual():

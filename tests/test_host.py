@@ -359,6 +359,13 @@ def _replay_ticket_table(items, mt, nb, tail, backward):
                 for cc in cols:
                     assert up[rr, cc] == pos(first), ("update out of order", t, up[rr, cc], pos(first))
                     up[rr, cc] += npan
+        elif typ == 5:  # the chain update of a tile from the split rows of the block right before its own
+            assert npan == 1 and r < mt and 0 <= cq < ctiles
+            Jt = cq // 8
+            assert cq - 8 * Jt < ct(Jt) and pos(J) == pos(Jt) - 1, ("a merged update that does not come from the previous block", t)
+            assert bs[r, J] == KQ, ("merged update before the split rows of its source block", t)
+            assert up[r, cq] == pos(J), ("merged update out of order", t)
+            up[r, cq] += 1
         elif typ == 1:  # diagonal-product tile
             assert r < mt and cq // 8 == J and cq - 8 * J < ct(J)
             assert bs[r, J] == KQ, ("diagonal product before its operand is split", t)
@@ -388,18 +395,19 @@ def test_persistent_solve_ticket_tables_only_wait_on_lower_tickets(mt, nb, tail,
     (cfg3: 8 x 32, cfg4: 8 x 64, cfg2: 8 x 8, the forest run: 29 x 11 with a 640-wide tail), degenerate ones and odd worker counts,
     forward and backward, by replaying the table against the kernel's wait conditions."""
     lib = _lib.load()
-    for backward in (0, 1):
+    for backward, merged in ((0, 1), (1, 1), (0, 0), (1, 0)):
         count = ctypes.c_int64(0)
-        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, None, 0, ctypes.byref(count)) == 0, lib.nngp_last_error()
+        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, merged, None, 0, ctypes.byref(count)) == 0, lib.nngp_last_error()
         buf = np.zeros((count.value, 4), np.int32)
-        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, buf.ctypes.data_as(ctypes.c_void_p), count.value,
+        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, merged, buf.ctypes.data_as(ctypes.c_void_p), count.value,
                                           ctypes.byref(count)) == 0, lib.nngp_last_error()
+        assert merged == int((buf[:, 0] & 15 == 5).any()) or (mt < 2 and merged == 1 and not (buf[:, 0] & 15 == 5).any())
         n, big = _replay_ticket_table([tuple(int(v) for v in row) for row in buf], mt, nb, tail, bool(backward))
         assert n == count.value
         assert big > 0 or mt < 2 or nb < 4, "no 256 x 256 bulk items in a shape that has room for them"
         # the table is a pure function of the shape: run-to-run bitwise reproducibility of the solves depends on it
         buf2 = np.zeros_like(buf)
-        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, buf2.ctypes.data_as(ctypes.c_void_p), count.value,
+        assert lib.nngp_trsm_ticket_order(mt, nb, tail, backward, workers, merged, buf2.ctypes.data_as(ctypes.c_void_p), count.value,
                                           ctypes.byref(count)) == 0
         assert np.array_equal(buf, buf2)
-    assert lib.nngp_trsm_ticket_order(0, 4, 8, 0, 512, None, 0, ctypes.byref(count)) != 0
+    assert lib.nngp_trsm_ticket_order(0, 4, 8, 0, 512, 1, None, 0, ctypes.byref(count)) != 0
