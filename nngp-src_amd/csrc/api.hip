@@ -1532,6 +1532,14 @@ int nngp_model_trsm_timer_read(nngp_model* m, int64_t* solves, double* ms_total,
 
 int nngp_model_residual_floor(nngp_model* m, double* ratio, int32_t* distrusted) {
     NNGP_REQUIRE(m != nullptr, "residual_floor: NULL model");
+    if (m->i8_guard_pending && m->ev_guard != nullptr) {  // the last level-1 batch's own estimate: wait for it and fold it in, so that a
+        NNGP_HIP_CHECK(hipEventSynchronize(m->ev_guard));  // caller can ask after a batch whether THAT batch tripped the guard
+        double r = 0.0;
+        memcpy(&r, m->i8_guard_host, sizeof(double));
+        m->i8_guard_pending = false;
+        if (r > m->i8_floor_ratio) m->i8_floor_ratio = r;
+        if (!(r <= kI8FloorThr)) m->i8_distrusted = true;
+    }
     if (ratio) *ratio = m->i8_checked ? m->i8_floor_ratio : -1.0;
     if (distrusted) *distrusted = m->i8_distrusted ? 1 : 0;
     return 0;

@@ -635,8 +635,14 @@ int lookahead_create(LookAhead** out) {
     for (auto e : all)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
     for (int i = 0; i < LookAhead::kMaxSteps; ++i) {
+        // (the seven events per step of round 4's schedule with the panel solves off the update stream exist in the knobs build only:
+        // that schedule never runs in the product library)
+#ifdef NNGP_TIMING_KNOBS
         hipEvent_t* per[11] = {&la->ev_panel[i], &la->ev_col[i], &la->ev_chunk[i], &la->ev_helper[i], &la->ev_far[i],
                                &la->ev_near[i],  &la->ev_tc[i],  &la->ev_tb[i],    &la->ev_split[i],  &la->ev_gp[i], &la->ev_c1[i]};
+#else
+        hipEvent_t* per[4] = {&la->ev_panel[i], &la->ev_col[i], &la->ev_chunk[i], &la->ev_helper[i]};
+#endif
         for (auto e : per)
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 set_error("hipEventCreate failed");
