@@ -504,7 +504,7 @@ def main():
             (rep,) = max_over_ranks([(time.perf_counter() - tr) / 2 * 1e3])
             shard_report["replicate_layout_ms_per_step"] = round(rep, 3)
 
-    traffic, traffic_src, k_traffic, r_traffic = None, None, None, None
+    traffic, traffic_src, k_traffic, r_traffic, t_traffic = None, None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg_name)
     traffic_note = None
     if os.path.exists(tpath):  # HBM bytes of the Cholesky kernels of one step (rocprofv3 --pmc, scripts/gpu_pmc.sh)
@@ -527,6 +527,8 @@ def main():
         traffic_src = traffic_note or "profiles/pmc_traffic_%s.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % cfg_name
         _r = _pm.get("kernels", {}).get("k_gemm_nt_i8s")
         r_traffic = (_r["fetch_bytes"] + _r["write_bytes"]) / _r["calls"] if _r and _r.get("calls") else None
+        _t = _pm.get("kernels", {}).get("k_trsm_tickets")
+        t_traffic = (_t["fetch_bytes"] + _t["write_bytes"]) / _t["calls"] if _t and _t.get("calls") else None
     if rank == 0:
         fl = flop_model(n, d, m, n_relu)
         ms = elapsed / args.steps * 1e3
@@ -639,6 +641,7 @@ def main():
             # the posterior's blocked triangular solves: one persistent, ticket-ordered launch each since round 5 (csrc/trsm_tickets.hip),
             # HIP events on the caller's stream around each solve
             s_tf = stimer["flops"] / (stimer["ms"] * 1e-3) / 1e12
+            n_pad, m_pad = -(-n // 128) * 128, -(-(m1 - m0) // 128) * 128
             result["roofline_solves"] = {
                 "bound": "mfma", "achieved": round(s_tf, 1), "peak": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
                 "frac": round(s_tf / (PEAK_F16_MFMA_TFLOPS / 3.0), 4),
@@ -646,6 +649,10 @@ def main():
                           "tiles, 128 x 128 diagonal-product and chain tiles, row splits, all drawn from a ticket counter), N^2 M "
                           "algorithmic flops per solve",
                 "solves_per_step": round(stimer["solves"] / args.steps, 2), "ms_per_step": round(stimer["ms"] / args.steps, 3),
+                # algorithmic bytes of one solve: the factor's split copy read once (lower triangle, 4 bytes an entry) + the right-hand
+                # sides read and written once; the counters show what the 128 / 256-row tiles actually move through the fabric
+                "algorithmic_bytes_per_launch": round(2.0 * n_pad * n_pad + 8.0 * m_pad * n_pad, 1),
+                "traffic": t_traffic, "traffic_source": (traffic_src + ", k_trsm_tickets, per launch") if t_traffic else traffic_note,
                 "note": "a dependency chain of N / 1024 block columns (DESIGN.md section 4); the solves share the chip with the alpha CG (from "
                         "the predict's start) and the first two with the cut of K's digit planes",
                 "timer": "HIP events on the caller's stream around each solve (library: nngp_model_trsm_timer), timed steps only",

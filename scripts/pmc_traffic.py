@@ -30,7 +30,7 @@ def short(name):
                 "k_gemm_nt_f32<1, 1, true>", "k_gemm_nt_f64", "k_potrf_leaf", "k_build", "k_gemv_f64", "k_gemv_n_f32",
                 "k_gemv_t_partial_f32", "k_factor_input", "k_transpose_f32", "k_gemm_nt_h3v2<true", "k_gemm_nt_h3v2<false", "k_gemm_nt_h3<true>", "k_gemm_nt_h3<false>", "k_split_rows",
                 "k_trsm_panel_f32", "k_trsm_panel_h3", "k_split_diag_frag", "k_symv_tiles_f64", "k_symv_reduce_f64", "k_split_lower_t",
-                "k_gemm_nt_i8s", "k_i8s_slice_rows", "k_i8s_slice_sym", "k_i8s_combine"):
+                "k_gemm_nt_i8s", "k_i8s_slice_rows", "k_i8s_slice_sym", "k_i8s_combine", "k_trsm_tickets"):
         if key in name:
             return {"k_gemm_nt_h3v2<true": "k_gemm_nt_h3v2<true>", "k_gemm_nt_h3v2<false": "k_gemm_nt_h3v2<false>"}.get(key, key)
     return None
