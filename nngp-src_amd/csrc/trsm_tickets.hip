@@ -82,6 +82,7 @@ struct TkParams {
     int backward;
     unsigned long long spin_ticks;  // bound of every wait, in s_memrealtime ticks (100 MHz)
     unsigned spin_max;              // ... and in polls (a second bound that does not depend on a clock)
+    int fault_ticket;               // test hook: the item with this ticket is processed but never published (-1: none)
 };
 
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -647,10 +648,11 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int a = 0; a < done_n; ++a) {
-                atomicAdd(done_counter + a, done_add);
-                if (done_stride2 != 0) atomicAdd(done_counter + done_stride2 + a, done_add);
-            }
+            if (ticket != P.fault_ticket)
+                for (int a = 0; a < done_n; ++a) {
+                    atomicAdd(done_counter + a, done_add);
+                    if (done_stride2 != 0) atomicAdd(done_counter + done_stride2 + a, done_add);
+                }
             s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
         }
         __syncthreads();
@@ -1157,6 +1159,11 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     P.backward = backward ? 1 : 0;
     P.spin_ticks = 200000000ULL;  // 2 s
     P.spin_max = 1u << 22;        // > 4 s of polls at ~1 us each
+    P.fault_ticket = -1;
+    if (const char* f = getenv("NNGP_TK_FAULT")) {  // test hook (tests/test_gpu_parity.py): lose one item's completion, give up after 50 ms
+        P.fault_ticket = atoi(f);
+        P.spin_ticks = 5000000ULL;
+    }
     const int64_t used = SY_COUNTERS + 3LL * mt * nb + (int64_t)mt * P.ctiles;
     NNGP_REQUIRE(used <= tk->sync_ints, "tk_solve: counter block overflow");
     // the error word survives (sticky until the host has read it); ticket and counters restart

@@ -6,6 +6,7 @@ answer); variances 1e-3 relative (float32 triangular solve); float32 MFMA GEMM i
 on integer data and to float32 rounding on random data.
 """
 import json
+import time
 import os
 
 import numpy as np
@@ -1184,4 +1185,38 @@ def test_early_stopped_cg_mean_correction():
     mean_only = model.predict(xt, cov=False)
     assert G.mean_gate(mean_only, mean_ref)[0] < 1e-9
     np.testing.assert_allclose(mean_only, mean, rtol=1e-6, atol=1e-6 * np.abs(mean).max())
+    model.close()
+
+
+def test_a_lost_completion_in_a_persistent_solve_costs_an_error_code_not_the_gpu():
+    """Round 5: each blocked triangular solve of the posterior (reference: the cho_solve inside predict_fn, train.py:157-158) is one
+    persistent launch whose workgroups wait on device counters (csrc/trsm_tickets.hip).  Every wait is bounded: here one item's
+    completion is deliberately lost (test hook NNGP_TK_FAULT: ticket 40 is processed but never published, waits give up after 50 ms
+    instead of 2 s).  The launch must drain by itself -- every workgroup sees the error word at its next poll or ticket -- the next
+    call on the model must return the error code with a message, and the model must then serve correct results through the
+    step-by-step solves."""
+    import scipy.linalg as sla
+    n, rows = 9300, 1024   # (1024 x 9344 right-hand-side entries: above the threshold of the float16-pipe solves)
+    x, y = synth.synthetic_queries(n, 24, seed=51)
+    model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+    a32, _ = model.factor_buffers()
+    L = torch.tril(a32[:n, :n]).double().cpu().numpy()
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((rows, n)).astype(np.float32)
+    good = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev())).cpu().numpy().astype(np.float64)   # the healthy persistent solve
+    os.environ["NNGP_TK_FAULT"] = "40"
+    try:
+        t0 = time.perf_counter()
+        model.apply_factor(torch.from_numpy(B.copy()).to(G.dev()))      # enqueues the faulty launch: asynchronous, no error yet
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 5.0, "the launch did not drain within its bounded waits"
+    finally:
+        del os.environ["NNGP_TK_FAULT"]
+    with pytest.raises(Exception) as err:                                # the next call reports it ...
+        model.apply_factor(torch.from_numpy(B.copy()).to(G.dev()))
+    assert "gave up waiting" in str(err.value)
+    X = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev())).cpu().numpy().astype(np.float64)   # ... and the model goes on, step by step
+    Xref = sla.solve_triangular(L, B.astype(np.float64).T, lower=True).T
+    assert np.linalg.norm(X - Xref) <= 2e-3 * np.linalg.norm(Xref)
+    assert np.linalg.norm(good - Xref) <= 2e-3 * np.linalg.norm(Xref)
     model.close()

@@ -411,3 +411,28 @@ def test_persistent_solve_ticket_tables_only_wait_on_lower_tickets(mt, nb, tail,
                                           ctypes.byref(count)) == 0
         assert np.array_equal(buf, buf2)
     assert lib.nngp_trsm_ticket_order(0, 4, 8, 0, 512, 1, None, 0, ctypes.byref(count)) != 0
+
+
+def test_persistent_solve_kernel_has_no_loop_the_threads_of_a_wave_leave_apart(tmp_path):
+    """The first GPU run of csrc/trsm_tickets.hip hung with every workgroup holding its first ticket: hipcc had threaded thread 0's
+    path (publish -> next ticket) across the back edge of the item loop, which turned the rest of the loop into an INNER loop that the
+    other threads of wave 0 never leave -- lane 0 then waits for its wave to reconverge, forever, outside every bounded wait.  The
+    kernel now has one thread-0 block per iteration; this test keeps it that way by looking at what hipcc makes of it: the item loop
+    at depth 1 and, inside it, only the poll loop, the stage loops and the barrier-only loop at depth 2 -- no depth-3 loop."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "nngp-src_amd", "csrc", "trsm_tickets.hip")
+    out = str(tmp_path / "tk.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    text = open(out).read()
+    start = text.index("k_trsm_tickets")
+    end = text.index(".end_amdhsa_kernel", start) if ".end_amdhsa_kernel" in text[start:] else len(text)
+    body = text[start:end]
+    body = body[:body.index("s_endpgm")] if "s_endpgm" in body else body
+    depths = [int(m) for m in re.findall(r"Loop Header: Depth=(\d+)", body)]
+    assert depths and max(depths) == 2 and depths.count(1) == 1, depths
+    assert "s_memrealtime" in body and "buffer_inv sc1" in body and "buffer_wbl2 sc1" in body   # bounded polls, acquire, release
