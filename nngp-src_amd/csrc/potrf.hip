@@ -248,17 +248,26 @@ __device__ unsigned long long g_leaf_stamps[4 * 16];  // per wave: cycles from k
 #else
 #define LEAF_STAMP(idx) do { } while (0)
 #endif
+template <int FORM>
 __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, float* dinv, int32_t* clamped,
                                                              float pivot_floor) {
     __shared__ float Lb[10 * BLK];
     __shared__ float Xb[10 * BLK];
     __shared__ float Tb[6 * BLK];   // scratch of the inverse assembly
-    __shared__ float ring[16 * 64];  // line j/2: columns j and j+1 of the current diagonal sub-block before elimination step j (layout: see rd)
-    __shared__ int step_flag;        // column pairs published so far: 16 jb + j/2 + 1
+    // FORM 1: word (j, lane) = the A operand of step j for the followers (low half; see below) tagged with the step number (high half)
+    // FORM 0: as floats, line j/2: columns j and j+1 of the current diagonal sub-block before elimination step j (layout: see rd)
+    __shared__ unsigned long long ring64[32 * 64];
+    __shared__ float ring_inv[32];   // FORM 1: 1 / L[j][j] of the sub-block column being eliminated
+    __shared__ int step_flag;        // FORM 0: column pairs published so far: 16 jb + j/2 + 1
+    float* ring = reinterpret_cast<float*>(ring64);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = tid >> 3, lc = (tid & 7) * 4;  // this thread's (row, first column) inside a 32x32 sub-block
     if (tid == 0) step_flag = 0;
+    if (FORM == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ring64[k * 256 + tid] = 0ull;  // no stale tag may look like a published step
+    }
 #ifdef NNGP_TIMING_KNOBS
     const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -291,11 +300,100 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
     const int i = lane & 31, h = lane >> 5;
     // Lane (i, h) owns the entries of row i in the columns of parity h: b[m] = entry (i, 2m + h) of block (wave, jb) -- the two
     // half-waves split the rank-1 updates between them instead of duplicating them.
-    float b[16], pinv[32];  // pinv[j] = 1 / L[j][j] of the sub-block this wave led
+    float b[16], pinv[32];  // pinv[j] = 1 / L[j][j] of the sub-block this wave led (FORM 0)
+    float invl = 0.0f;      // FORM 1: lane c (both halves): 1 / L[c][c] of the sub-block this wave led
     const float* rd = ring + h * 32;  // a column pair is stored by row parity: entry (k, A|B) at ((k & 1) * 16 + (k >> 1)) * 2 + (A: 0, B: 1)
 #pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
-        if (wave >= jb) {
+        f32x16 acc;
+        if (FORM == 1 && wave >= jb) {
+            // Round 5: the sub-blocks stay in the MFMA accumulator layout for the 32 steps and every step is ONE rank-1
+            // v_mfma_f32_32x32x2_f32 per wave -- no LDS round trip and no per-element FMAs in the leader's chain (readlane of the
+            // pivot -> v_rsq_f32 -> one multiply -> MFMA: 54 ns a step against 75 with a separate flag behind a release,
+            // scripts/micro/mfma_chain.hip).  The leader holds the diagonal sub-block S as a full symmetric matrix: row j of S IS
+            // column j, already one entry per lane (lanes of half hj), which is the layout of both MFMA operands; the finished
+            // columns are frozen by zeroing the operand there, so at the end entry (m, c), c < m, holds L[m][c] / inv_c.  A follower
+            // holds its sub-block TRANSPOSED and UNSCALED (accumulator row j = column j of the block before its division by
+            // L[j][j]): that row is the B operand as it stands, the A operand is the leader's -L[.][j] / L[j][j], published as
+            // ONE 8-byte word per lane {value, step number} -- value and tag arrive together, so neither side orders anything: no
+            // flag, no release wait in the leader, one LDS round trip per step in the follower.
+            const bool leader = (wave == jb);
+            float* Bw = Lb + blk(wave, jb) * BLK;
+            if (leader) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {  // the full symmetric block from its lower triangle
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    acc[r] = Bw[(i <= row) ? row * LS + i : i * LS + row];
+                }
+                const float floor_eff = pivot_floor > 0.0f ? pivot_floor : 1.0e-30f;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;  // accumulator register / lane half that hold row j
+                    const float xr = acc[rj];
+                    const float xm = (h == hj && i > j) ? xr : 0.0f;  // rows below the pivot (beside the rsq, not behind it)
+                    const float d_raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xr), 32 * hj + j));
+                    const float inv = __builtin_amdgcn_rsqf(fmaxf(d_raw, floor_eff));  // v_rsq_f32, ~1 ulp: ample for a preconditioner
+                    const float x = xm * inv;  // L[i][j]
+                    const float xn = xm * -inv;
+                    // (the publish goes in FRONT of the MFMA: behind it the LDS store waits for its data while the MFMA streams the
+                    // accumulator through the register file -- 80 cycles a step against ~12)
+                    if (jb < 3) {  // (the last sub-block column has no followers)
+                        const float xq = xn * inv;
+                        const unsigned long long word = ((unsigned long long)(unsigned)(jb * 32 + j + 1) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, xq);
+                        __hip_atomic_store(&ring64[j * 64 + lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xn, x, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // Nothing but the chain was kept per step: entry (c, c) of the accumulator was frozen at step c and IS the pivot of
+                // column c as the chain read it, so every lane redoes its own column's clamp and v_rsq_f32 (same instructions on the
+                // same value: the same bits) -- 1 / L[c][c] for the scaling below, for the followers and for this wave's inverse.
+                float dsel = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsel = ((r & 3) + 8 * (r >> 2) + 4 * h == i) ? acc[r] : dsel;
+                const float dother = __shfl_xor(dsel, 32);
+                const float d_raw = (((i >> 2) & 1) == h) ? dsel : dother;  // the half whose rows include row i holds it
+                nclamp += __builtin_popcount((unsigned)__ballot(!(d_raw > pivot_floor)));  // lanes 0 .. 31: one per column
+                const float dcl = fmaxf(d_raw, floor_eff);  // (a NaN pivot is clamped as well)
+                invl = __builtin_amdgcn_rsqf(dcl);
+                const float diagl = dcl * invl;
+                if (jb < 3 && lane < 32) ring_inv[lane] = invl;  // (the followers read it behind the barrier below)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Bw[row * LS + i] = (i < row) ? acc[r] * invl : (i == row ? diagl : 0.0f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = Bw[i * LS + (r & 3) + 8 * (r >> 2) + 4 * h];  // transposed
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int rj = (j & 3) + 4 * (j >> 3), hj = (j >> 2) & 1;
+                    const int target = jb * 32 + j + 1;
+                    const float bq = (h == hj) ? acc[rj] : 0.0f;  // this wave's column j, not yet divided by L[j][j]
+                    unsigned long long word;
+                    for (;;) {  // every lane waits for its own word
+                        word = __hip_atomic_load(&ring64[j * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if ((int)(word >> 32) == target) break;
+                    }
+                    const float a = __builtin_bit_cast(float, (unsigned)word);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+                }
+            }
+        }
+        if (FORM == 1) {
+            __syncthreads();  // the leader's 1 / L[j][j] are in place
+            if (wave > jb) {
+                float* Bw = Lb + blk(wave, jb) * BLK;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // column of the block
+                    Bw[i * LS + row] = acc[r] * ring_inv[row];
+                }
+            }
+        }
+        if (FORM == 0 && wave >= jb) {
             const bool leader = (wave == jb);
             float* Bw = Lb + blk(wave, jb) * BLK;
 #pragma unroll
@@ -395,6 +493,9 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
     // Column-oriented forward substitution: once x[k] is known every later row's sum takes its term, s[r] += L[r][k] x[k] --
     // independent FMAs (the row-oriented form is a dependent chain per row and ran 7.7k-12k cycles depending on how hipcc
     // scheduled its LDS reads); the dependent chain is one FMA + one multiply per k.
+    // (Measured and dropped, round 5: a second accumulator Y = I in the LEADER that takes every step like a follower's block ends as
+    // L^-1 and this phase disappears -- but a second MFMA per step costs the chain-carrying wave 85 cycles of matrix pipe
+    // (scripts/micro/mfma_chain.hip: 128 -> 211 cycles a step), the column phases grew by more than the 8.5k cycles saved.)
     {
         const float* Djj = Lb + blk(wave, wave) * BLK;
         float* Xjj = Xb + blk(wave, wave) * BLK;
@@ -413,7 +514,8 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
                 for (int r = k + 3; r < 32; ++r) lcol[(k + 2) % 3][r] = Djj[r * LS + k + 2];
             }
             __builtin_amdgcn_sched_barrier(0);
-            x[k] = (((i == k) ? 1.0f : 0.0f) - sacc[k]) * pinv[k];
+            const float pk = FORM == 1 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, invl), k)) : pinv[k];
+            x[k] = (((i == k) ? 1.0f : 0.0f) - sacc[k]) * pk;
 #pragma unroll
             for (int r = k + 1; r < 32; ++r) sacc[r] = fmaf(lcol[k % 3][r], x[k], sacc[r]);
             __builtin_amdgcn_sched_barrier(0);
@@ -502,7 +604,12 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
 int launch_potrf_leaf(float* a, int64_t ld, float* dinv_block, int32_t* clamped, float pivot_floor, hipStream_t s) {
     if (NNGP_KNOB(3) != 1 && NNGP_KNOB(3) != 2)
     {
-        hipLaunchKernelGGL(k_potrf_leaf_panel, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor);
+        #ifdef NNGP_TIMING_KNOBS
+        if (NNGP_KNOB(3) == 3)  // A/B: round 4's column phases (column pairs through an LDS ring, per-lane FMAs)
+            hipLaunchKernelGGL(k_potrf_leaf_panel<0>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor);
+        else
+#endif
+            hipLaunchKernelGGL(k_potrf_leaf_panel<1>, dim3(1), dim3(256), 0, s, a, ld, dinv_block, clamped, pivot_floor);
 #ifdef NNGP_TIMING_KNOBS
         if (NNGP_KNOB(7) == 8) {  // timing study: per wave, cycles from kernel start to the end of each phase
             unsigned long long h[64];
