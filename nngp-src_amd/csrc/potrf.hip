@@ -39,13 +39,17 @@ __device__ __forceinline__ constexpr int blk(int ib, int jb) { return ib * (ib +
 template <bool NN>
 __device__ __forceinline__ f32x16 blk_mma(const float* ab, const float* bb, f32x16 acc, float sign, int lane) {
     const int r = lane & 31, h = lane >> 5;
+    // all 32 operand reads first, then the 16 MFMAs back to back (interleaved, each MFMA waited for its own LDS round trip)
+    float av[16], bv[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int k = 2 * s + h;
-        const float a = sign * ab[r * LS + k];
-        const float b = NN ? bb[k * LS + r] : bb[r * LS + k];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        av[s] = ab[r * LS + k];
+        bv[s] = NN ? bb[k * LS + r] : bb[r * LS + k];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sign * av[s], bv[s], acc, 0, 0, 0);
     return acc;
 }
 
@@ -577,8 +581,8 @@ __global__ __launch_bounds__(256) void k_potrf_leaf_panel(float* A, int64_t ld, 
 
     LEAF_STAMP(10);
     // ---- write back: L into the lower triangle of A, X (with its zero upper blocks) into dinv ----
-#pragma unroll 1
-    for (int b = 0; b < 16; ++b) {
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {  // (unrolled: rolled up, every block waited for its own LDS and store round trips)
         const int ib = b >> 2, jb = b & 3;
         float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
         if (jb <= ib) {
