@@ -1669,6 +1669,31 @@ static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t
     const int64_t n = m->n, np = m->np, mp = round_up(mt, TB);
     const bool compact_train = on_train && m->ld != m->np;  // K_dd rows have stride ld: copy them to the compact cross buffer
     NNGP_TRY(ensure_predict_capacity(m, mt, !on_train || compact_train));
+    // A predict whose covariance will take the int8 residual product right after a fit: the digit planes of K (13 N^2 bytes of HBM
+    // traffic, 2.7 ms alone at N = 32768) are cut beside the predict's first kernels.  The cut's workgroups hold 132 KB of LDS and cannot
+    // share a compute unit with a workgroup of the persistent solves, so what is left of it when the first solve starts waits for the
+    // gaps between and behind the solves: it is enqueued FIRST (round 5: before the cross kernel and the inverted blocks, on the
+    // look-ahead's idle update stream -- it needs nothing but K) and has the chip until then.  (debug key 5 = 53: in stream order
+    // where the planes are first needed)
+    if (cov_mode != NNGP_COV_NONE && m->var_refine >= 1 && use_i8s(m, mp) && !(m->serving_ready && !is_ntk) && NNGP_KNOB(5) != 53) {
+        if (cov_mode == NNGP_COV_FULL && use_i8s_fine(m, mp)) m->i8_want_fine = true;  // a full covariance runs at level >= 2: later residuals
+        const int rc_i8 = ensure_i8s(m, mp, m->i8.k, i8s_planes_policy(m));
+        if (rc_i8 != 0 && rc_i8 != 1) return rc_i8;
+        if (rc_i8 == 0 && !m->i8.k.ready) {
+            if (m->ev_i8 == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_i8, hipEventDisableTiming));
+            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, s));  // K is complete; earlier readers of the planes are behind us
+            // With the alpha CG running from the predict's start (cg_from_the_start) the cut must not sit in front of it on the solve
+            // stream, nor in front of the inverted blocks on the panel stream
+            static const int cut_env = getenv("NNGP_TK_CUTSTREAM") ? atoi(getenv("NNGP_TK_CUTSTREAM")) : 2;  // (development aid)
+            hipStream_t cs = m->solve_stream;
+            if (cut_env != 0 && cg_from_the_start(m, mp) && m->la != nullptr && m->la->panel != nullptr)
+                cs = (cut_env == 2 && m->la->update != nullptr) ? m->la->update : m->la->panel;
+            NNGP_HIP_CHECK(hipStreamWaitEvent(cs, m->ev_i8, 0));
+            NNGP_TRY(i8s_cut_planes(m, m->i8.k, m->k64, m->ld, cs));
+            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, cs));
+            m->i8_k_pending = true;
+        }
+    }
     NNGP_TRY(tri_fork(m, s));  // first predict of a fit: the factor's inverted blocks are built beside the cross-kernel build
 
     // ---- cross kernel of `get` and the mean: mu = K_td alpha (float64) ----
@@ -1691,27 +1716,6 @@ static int predict_impl(nngp_model* m, const double* x_test, int64_t mt, int32_t
     // (overlapping it), and the mean follows once alpha is there.
     // Levels >= 2 check afterwards whether the fixed number of correction sweeps was enough (cov_adaptive below):
     // 0 nothing to check, 1 NNGP diag, 2 NNGP full, 3 NTK, 4 NNGP diag at level 1.
-    // A predict whose covariance will take the int8 residual product right after a fit: the digit planes of K (13 N^2 bytes of HBM
-    // traffic) are cut on the solve stream while this stream runs the first two blocked solves, whose launches leave most of the
-    // chip's bandwidth and, between them, its compute units idle.  (debug key 5 = 53: in stream order where they are first needed)
-    if (cov_mode != NNGP_COV_NONE && m->var_refine >= 1 && use_i8s(m, mp) && !(m->serving_ready && !is_ntk) && NNGP_KNOB(5) != 53) {
-        if (cov_mode == NNGP_COV_FULL && use_i8s_fine(m, mp)) m->i8_want_fine = true;  // a full covariance runs at level >= 2: later residuals
-        const int rc_i8 = ensure_i8s(m, mp, m->i8.k, i8s_planes_policy(m));
-        if (rc_i8 != 0 && rc_i8 != 1) return rc_i8;
-        if (rc_i8 == 0 && !m->i8.k.ready) {
-            if (m->ev_i8 == nullptr) NNGP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_i8, hipEventDisableTiming));
-            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, s));  // K is complete; earlier readers of the planes are behind us
-            // With the alpha CG running from the predict's start (cg_from_the_start) the cut must not sit in front of it on the solve
-            // stream: it goes to the look-ahead's panel stream (idle between factorisations; the factor's inverted blocks were just
-            // queued there by tri_fork)
-            static const int cut_env = getenv("NNGP_TK_CUTSTREAM") ? atoi(getenv("NNGP_TK_CUTSTREAM")) : 1;  // (development aid)
-            hipStream_t cs = (cut_env != 0 && cg_from_the_start(m, mp) && m->la != nullptr && m->la->panel != nullptr) ? m->la->panel : m->solve_stream;
-            NNGP_HIP_CHECK(hipStreamWaitEvent(cs, m->ev_i8, 0));
-            NNGP_TRY(i8s_cut_planes(m, m->i8.k, m->k64, m->ld, cs));
-            NNGP_HIP_CHECK(hipEventRecord(m->ev_i8, cs));
-            m->i8_k_pending = true;
-        }
-    }
     if (m->i8_guard_pending && hipEventQuery(m->ev_guard) == hipSuccess) {  // the previous level-1 batch's estimate has arrived
         double ratio = 0.0;
         memcpy(&ratio, m->i8_guard_host, sizeof(double));
