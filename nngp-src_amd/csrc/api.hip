@@ -2092,7 +2092,11 @@ int h3_scratch_get(hipStream_t s, size_t bytes, char** out) {
             if (!c.used && e == nullptr) e = &c;
     if (e == nullptr) {  // every slot belongs to another stream: take the first one over once its work is through
         e = &g_h3_scratch[0];
-        NNGP_HIP_CHECK(hipStreamSynchronize(e->stream));
+        // (the stored handle may belong to a stream its owner has destroyed since: then the whole device is waited for instead)
+        if (hipStreamSynchronize(e->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            NNGP_HIP_CHECK(hipDeviceSynchronize());
+        }
         (void)hipFree(e->p);
         *e = H3Scratch();
     }

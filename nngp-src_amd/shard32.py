@@ -42,6 +42,7 @@ class HipRowOps:
         self.n, self.d = int(n), int(d)
         n_cap = D.row_chunk(n, world) * world
         self.model = GPModel(n_cap, d, w_std, b_std, get="nngp", diag_reg=diag_reg, diag_reg_absolute_scale=diag_reg_absolute_scale)
+        self._zpad = None  # padded float64 copy of the current Z block (rows_times)
         self.arch = _lib.make_arch(w_std, b_std)
         self._x = None
 
@@ -141,12 +142,22 @@ class HipRowOps:
             return out
         # the GEMM works on multiples of 128: pad the operands (zero rows / columns contribute nothing)
         mp, nrp, kp = -(-m // 128) * 128, -(-nr // 128) * 128, -(-self.n // 128) * 128
-        zp = self.torch.zeros((mp, kp), dtype=self.torch.float64, device=self.device)
+        # one padded copy of z, kept between calls; the kernel rows are read where they lie (their padding columns are zero; rows past
+        # r1 inside the last 128-row tile only feed output columns that are cut off below) unless the tile would leave the buffer
+        if self._zpad is None or self._zpad.shape != (mp, kp):
+            self._zpad = self.torch.zeros((mp, kp), dtype=self.torch.float64, device=self.device)
+        zp = self._zpad
         zp[:m, :self.n] = z
-        kp_rows = self.torch.zeros((nrp, kp), dtype=self.torch.float64, device=self.device)
-        kp_rows[:nr, :self.n] = kbuf[r0:r1, :self.n]
+        if mp > m:
+            zp[m:].zero_()
+        if r0 + nrp <= kbuf.shape[0] and kp <= ld:
+            kp_rows, kld = kbuf[r0:], ld
+        else:
+            kp_rows = self.torch.zeros((nrp, kp), dtype=self.torch.float64, device=self.device)
+            kp_rows[:nr, :self.n] = kbuf[r0:r1, :self.n]
+            kld = kp
         c = self.torch.zeros((mp, nrp), dtype=self.torch.float64, device=self.device)
-        L.check(self.lib.nngp_gemm_nt_f64(L.ptr(c), nrp, L.ptr(c), nrp, L.ptr(zp), kp, L.ptr(kp_rows), kp, mp, nrp, kp, 1.0, 0.0,
+        L.check(self.lib.nngp_gemm_nt_f64(L.ptr(c), nrp, L.ptr(c), nrp, L.ptr(zp), kp, L.ptr(kp_rows), kld, mp, nrp, kp, 1.0, 0.0,
                                           L.stream_ptr()), self.lib)
         out.copy_(c[:m, :nr])
         return out
@@ -213,8 +224,9 @@ class RowShardedGP:
         ops, t = self.ops, self.torch
         self.reg = float(ops.set_train(self.x, self.y))
         ops.build_rows(self.r0, self.r1)
-        shift = 1.0
+        shift, factored_shift, clamped = 1.0, 1.0, 0
         for attempt in range(5):
+            factored_shift = shift
             ops.factor_input_rows(self.r0, self.r1, shift)
             if self.world > 1:
                 buf = ops.factor_input_buffer()
@@ -226,7 +238,10 @@ class RowShardedGP:
             if clamped == 0:
                 break
             shift *= 16.0
-        self.shift_scale = shift
+        if clamped != 0:  # (nngp_model_factor alone gives up the same way: a preconditioner with clamped pivots is not trusted)
+            raise RuntimeError("shard32.fit: the float32 factor still has %d clamped pivots with the regulariser shift raised %g-fold"
+                               % (clamped, factored_shift))
+        self.shift_scale = factored_shift  # the shift that WAS factored (it scales the CG's iteration limit)
         self.alpha = self._pcg(ops.to_device(self.y))
         ops.set_alpha(self.alpha, self.cg_iters, self.relres)
         return self
