@@ -361,6 +361,15 @@ int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode,
  * needed; items == NULL only counts.  tests/test_host.py replays the tables against the kernel's own wait conditions. */
 int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged,
                            int32_t* items /* host, 4 * cap */, int64_t cap, int64_t* count /* host */);
+/* The same table as the product launches it on MI355X: `queues` = 8 tables, one per XCD -- a workgroup draws from the table of the XCD
+ * it runs on (and from the others' once its own has run out), so that the items which read one pair of row tiles' split rows meet in one
+ * L2.  `items` is the GLOBAL start order of the host's schedule (every item's dependencies precede it there), queue_of[i] the table item
+ * i is in; a table holds its items in that order.  Hang freedom: the earliest unfinished item of the global order is at the head of its
+ * table, whose workgroups hold nothing later than it.  queues = 1: nngp_trsm_ticket_order.  tests/test_host.py replays both properties
+ * and runs the draw protocol with random item durations and worker counts. */
+int nngp_trsm_ticket_queues(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged,
+                            int32_t queues /* 1 or 8 */, int32_t* items /* host, 4 * cap */, int32_t* queue_of /* host, cap */, int64_t cap,
+                            int64_t* count /* host */);
 /* B[m, n] <- B L^-T using the factor and dinv from nngp_potrf_f32 (m, n multiples of 128). */
 int nngp_trsm_rlt_f32(float* b, int64_t ldb, int64_t m, const float* l, int64_t ldl, const float* dinv,
                       int64_t n, void* stream);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "nngp_encoder_encode", "nngp_comm_unique_id", "nngp_comm_create", "nngp_comm_destroy", "nngp_comm_library",
     "nngp_allgather_rows", "nngp_bcast", "nngp_model_update_timer", "nngp_model_update_timer_read", "nngp_symv_f64",
     "nngp_pool_select", "nngp_model_update_timer_bytes", "nngp_model_factor_update_cols", "nngp_gemm_nt_i8s", "nngp_model_residual_timer", "nngp_model_residual_timer_read", "nngp_model_trsm_timer", "nngp_model_trsm_timer_read", "nngp_model_residual_floor",
-    "nngp_trsm_ticket_order", "nngp_model_reserve", "nngp_alloc_count",
+    "nngp_trsm_ticket_order", "nngp_trsm_ticket_queues", "nngp_model_reserve", "nngp_alloc_count",
 )
 
 
@@ -149,6 +149,7 @@ def bind_prototypes(lib, knobs: bool = False):
     lib.nngp_model_reserve.argtypes = [vp, i64, i32]
     lib.nngp_alloc_count.argtypes = []
     lib.nngp_trsm_ticket_order.argtypes = [i32, i32, i32, i32, i32, i32, vp, i64, ctypes.POINTER(i64)]
+    lib.nngp_trsm_ticket_queues.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, ctypes.POINTER(i64)]
     lib.nngp_model_factor_update_cols.argtypes = [vp, i64, i64, ctypes.POINTER(i64), i32, i64, vp]
     for name in ABI_SYMBOLS:
         if name not in ("nngp_last_error", "nngp_model_factor_shift", "nngp_comm_library", "nngp_alloc_count"):

@@ -2054,7 +2054,12 @@ int nngp_model_apply_factor(nngp_model* m, float* b, int64_t rows, int32_t mode,
 
 int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged,
                            int32_t* items, int64_t cap, int64_t* count) {
-    return tk_order_export(row_tiles, block_cols, tail_tiles, backward, workers, merged, items, cap, count);
+    return tk_order_export(row_tiles, block_cols, tail_tiles, backward, workers, merged, 1, items, nullptr, cap, count);
+}
+
+int nngp_trsm_ticket_queues(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged,
+                            int32_t queues, int32_t* items, int32_t* queue_of, int64_t cap, int64_t* count) {
+    return tk_order_export(row_tiles, block_cols, tail_tiles, backward, workers, merged, queues, items, queue_of, cap, count);
 }
 
 int nngp_potrf_f32(float* a, int64_t n, int64_t ld, float* dinv, int32_t* clamped, void* stream) {

@@ -337,7 +337,8 @@ void tk_invalidate_inverses(TrsmTickets* tk);
 bool tk_usable(const TrsmTickets* tk, int64_t m, int64_t np);
 int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, const SplitWork& sw, bool backward, hipStream_t s, int reserve_cus = 0);
 int tk_poll_error(TrsmTickets* tk, bool wait);
-int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int merged, int32_t* out, int64_t cap, int64_t* count);  // error word of a launch that gave up waiting (0: none seen)
+int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int merged, int queues, int32_t* out, int32_t* queue_of, int64_t cap,
+                    int64_t* count);  // error word of a launch that gave up waiting (0: none seen)
 // y = (A + diag_add I) x for a SYMMETRIC n x n float64 matrix stored in full, reading only its lower triangle (half the bytes
 // of launch_gemv_f64); part: [ceil(n/128)][np] workspace, np = ceil(n/128)*128.  Deterministic (fixed summation order).
 int launch_symv_f64(const double* a, int64_t lda, int64_t n, const double* x, double* y, double diag_add, double* part,

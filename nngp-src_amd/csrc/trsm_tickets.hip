@@ -35,6 +35,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <functional>
 #include <queue>
 #include <vector>
 
@@ -57,7 +58,8 @@ constexpr int kBs = 1024;                // block-column width
 constexpr int kQ = 4;                    // split items per (r, J): 32 rows each (8 waves x 4 rows)
 
 enum { IT_SB = 0, IT_D = 1, IT_SX = 2, IT_U = 3, IT_UB = 4, IT_UW = 5 };
-enum { SY_TICKET = 0, SY_ERROR = 1, SY_COUNTERS = 16 };
+enum { SY_TICKET = 0, SY_ERROR = 1, SY_TICKETQ = 2, SY_COUNTERS = 16 };  // SY_TICKETQ .. + 7: one ticket counter per queue
+constexpr int kMaxQ = 8;
 
 struct TkParams {
     float* b;                 // right-hand sides [mt * 128, np], row stride ldb
@@ -74,8 +76,10 @@ struct TkParams {
     float* rinv_x;            // [nb][m_cap]
     float* rinv_d;
     int64_t r_stride;
-    const int4* items;
+    const int4* items;        // the queues' tables one behind the other
     int n_items;
+    int nq;                   // queues: 1, or 8 = one per XCD (a workgroup draws from the queue of the XCD it runs on)
+    int q_off[kMaxQ + 1];     // queue q = items[q_off[q] .. q_off[q + 1])
     int* sync;
     int mt, nb, ctiles, tail_ct;
     float l_iscale;           // 1 / scale of the factor's split copy
@@ -150,7 +154,30 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
     // across the back edge into the fetch block, which made the rest of the loop an INNER loop that the other threads never leave:
     // lane 0 of wave 0 waited for its wave's reconvergence, nothing was ever published (first GPU run of this kernel: every workgroup
     // holding its first ticket, no counter moving).
-    if (tid == 0) s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
+    // Queues (round 5): with nq = 8 the table is eight tables, one per XCD, and a workgroup draws from the table of the XCD it runs on
+    // (HW_REG_XCC_ID): the items of one pair of row tiles meet in one L2.  Every queue is consumed in its own order whoever draws
+    // from it -- a workgroup whose queue has run out goes on with the others' (the end of a solve, or an XCD without workgroups).
+    int my_q = 0;
+    if (P.nq > 1) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        my_q = (int)(xcc & 15u) % P.nq;
+    }
+    auto next_ticket = [&]() -> int {  // thread 0 only: index of the next item in P.items, or n_items when every queue is through
+        if (ld_agent(sync + SY_ERROR) != 0) return 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < kMaxQ; ++k) {  // (unrolled: no loop of thread 0's own inside the item loop, see above)
+            if (k >= P.nq) break;
+            int q = my_q + k;
+            if (q >= P.nq) q -= P.nq;
+            const int len = P.q_off[q + 1] - P.q_off[q];
+            if (ld_agent(sync + SY_TICKETQ + q) >= len) continue;  // (an exhausted queue's counter is left alone)
+            const int t = atomicAdd(sync + SY_TICKETQ + q, 1);
+            if (t < len) return P.q_off[q] + t;
+        }
+        return 0x7fffffff;
+    };
+    if (tid == 0) s_word = next_ticket();
     __syncthreads();
     int ticket = __builtin_amdgcn_readfirstlane(s_word);
     __syncthreads();
@@ -653,7 +680,7 @@ __global__ __launch_bounds__(512, 1) void k_trsm_tickets(TkParams P) {
                     atomicAdd(done_counter + a, done_add);
                     if (done_stride2 != 0) atomicAdd(done_counter + done_stride2 + a, done_add);
                 }
-            s_word = ld_agent(sync + SY_ERROR) != 0 ? 0x7fffffff : atomicAdd(sync + SY_TICKET, 1);
+            s_word = next_ticket();
         }
         __syncthreads();
         ticket = __builtin_amdgcn_readfirstlane(s_word);
@@ -748,7 +775,13 @@ __global__ __launch_bounds__(256) void k_transpose_1024(const float* __restrict_
 // tile by tile (128 x 128 items: four times the parallelism where only latency counts).  Tiles without a partner (odd row-tile count, odd tail)
 // take all their updates as 128 x 128 items.
 // merged: the chain update of a paired tile is a UW item (it waits for the split rows of the previous block B_J, not for X_J)
-void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, bool merged, std::vector<int4>& out) {
+// nq > 1: the workers are nq pools (the XCDs) with a table each.  A pair of row tiles belongs to 8 / (pairs) pools -- its bulk items are
+// dealt to them by column pair, its two chains to the first two -- so that everything that reads the split rows of X of one row pair
+// (1 MB per block column, read by every column pair's item) runs behind ONE L2, in the order in which it becomes ready: the items of one
+// block-column range over all column pairs are queued together and start together.  `queue_of` receives each item's pool; `out` stays
+// the global start order (an item's dependencies all precede it there).
+void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, bool merged, std::vector<int4>& out, int nq = 1,
+                    std::vector<int>* queue_of = nullptr) {
     const int ctiles = (nb - 1) * 8 + tail_ct;
     auto ct_of = [&](int J) { return J == nb - 1 ? tail_ct : 8; };
     auto pos_of = [&](int J) { return backward ? nb - 1 - J : J; };  // position of block column J in solve order (0 = solved first)
@@ -770,10 +803,27 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, boo
     struct Done {
         double t;
         int type, r, cq, J, npan;
+        int q = 0;
         bool operator<(const Done& o) const { return t > o.t; }
     };
-    std::priority_queue<Ready> ready;
+    if (nq < 1 || nq > kMaxQ) nq = 1;
+    std::vector<std::priority_queue<Ready>> ready_q((size_t)nq);
     std::priority_queue<Done> running;
+    const int mt2p = mt / 2;
+    const int per_pair = (mt2p >= 1 && mt2p <= nq && nq % mt2p == 0) ? nq / mt2p : 1;  // pools per pair of row tiles
+    auto pool_of = [&](int type, int r, int c) -> int {  // r: row tile (IT_UB: first of the pair), c: column tile (split items: anything)
+        if (nq == 1) return 0;
+        const int rp = r / 2;
+        if (rp >= mt2p) return r % nq;  // the unpaired last row tile
+        const int base = (rp * per_pair) % nq;
+        if (type == IT_UB) return base + (c / 2) % per_pair;
+        return base + (r % 2) % per_pair;  // a row tile's chain (splits, diagonal products, 128 x 128 updates)
+    };
+    struct ReadyProxy {  // the single-queue code below pushes here
+        std::vector<std::priority_queue<Ready>>* q;
+        std::function<int(int, int, int)> pool;
+        void push(const Ready& it) { (*q)[(size_t)pool(it.type, it.r, it.c)].push(it); }
+    } ready{&ready_q, pool_of};
     std::vector<int> up((size_t)mt * ctiles, 0);      // block columns applied to a tile (positions in solve order)
     std::vector<char> busy((size_t)mt * ctiles, 0);   // an update of the tile is queued or running
     std::vector<int> xs((size_t)mt * nb, 0), xd((size_t)mt * nb, 0), bs((size_t)mt * nb, 0), tiles_final((size_t)mt * nb, 0);
@@ -835,13 +885,16 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, boo
         for (int i = 0; i < n; ++i) ready.push(Ready{2 * pos_of(J), type == IT_D ? J * 8 + i : i, r, type, J, K_TILE});
     };
     for (int r = 0; r < mt; ++r) push_block_items(IT_SB, r, blk_at(0));
-    int free_workers = workers;
+    std::vector<int> free_q((size_t)nq, workers / nq > 0 ? workers / nq : 1);
     double now = 0.0;
     out.clear();
+    if (queue_of != nullptr) queue_of->clear();
     for (;;) {
-        while (free_workers > 0 && !ready.empty()) {
-            const Ready it = ready.top();
-            ready.pop();
+        for (int q = 0; q < nq; ++q)
+        while (free_q[(size_t)q] > 0 && !ready_q[(size_t)q].empty()) {
+            int& free_workers = free_q[(size_t)q];
+            const Ready it = ready_q[(size_t)q].top();
+            ready_q[(size_t)q].pop();
             int4 rec;
             Done d{};
             if (it.type == IT_UB) {
@@ -882,6 +935,8 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, boo
                 d = Done{now + dur, it.type, it.r, it.c, it.J, 1};
             }
             out.push_back(rec);
+            if (queue_of != nullptr) queue_of->push_back(q);
+            d.q = q;
             running.push(d);
             --free_workers;
         }
@@ -889,7 +944,7 @@ void tk_build_order(int mt, int nb, int tail_ct, bool backward, int workers, boo
         const Done d = running.top();
         running.pop();
         now = d.t;
-        ++free_workers;
+        ++free_q[(size_t)d.q];
         const int r = d.r;
         if (d.type == IT_SB) {
             if (++bs[(size_t)r * nb + d.J] == kQ) {
@@ -955,6 +1010,9 @@ struct TrsmTickets {
     int4* items[2] = {nullptr, nullptr};
     int64_t items_cap = 0;
     int n_items[2] = {0, 0};
+    int nq = 1;                   // queues of the item table: 8 (one per XCD) on a device with 8 XCDs of 32 compute units, else 1
+    int q_off[2][kMaxQ + 1] = {};
+    int nq_dir[2] = {1, 1};       // queues of the current tables
     int key_mt = 0, key_nb = 0, key_tail = 0;
     std::vector<int4> host_items[2];
     int* host_err = nullptr;      // pinned: error word of the last launches
@@ -1026,6 +1084,13 @@ int tk_create(TrsmTickets** out, int64_t np_cap, int64_t m_cap) {
     int dev = 0, count = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && count > 0)
         tk->workers = count;
+    // One queue.  NNGP_TK_QUEUES=8 (read when the model is created; a chip of 8 XCDs of 32 compute units only: workgroup i of a launch goes
+    // to XCD i % 8, HW_REG_XCC_ID names it): one table per XCD.  Measured at N = 32768, M = 1024 (profiles/r5_tk_queues_ab.txt): the
+    // launches fetch 16 % fewer bytes through the fabric (47.9 -> 40.1 GB for three solves: the split rows of X of a pair of row tiles are
+    // shared in one L2), bit-identical results, and take the same time (4.34 / 8.45 ms forward / both halves either way; in the step
+    // 13.8-13.9 ms against 13.65) -- a stage of a bulk item waits for its slowest piece, and the L panels still come from HBM.  Off.
+    tk->nq = 1;
+    if (const char* e = getenv("NNGP_TK_QUEUES")) tk->nq = (atoi(e) == 8 && tk->workers == 256) ? kMaxQ : 1;
     *out = tk;
     return 0;
 }
@@ -1097,15 +1162,19 @@ int tk_prepare_inverses(TrsmTickets* tk, const TriInv& ti, int64_t np, const flo
 
 // the ticket table of a shape, four ints per item {type | panels << 4, r, c or q, J}, for the host-side proof that every item's
 // dependencies hold lower tickets (tests/test_host.py)
-int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int merged, int32_t* out, int64_t cap, int64_t* count) {
-    NNGP_REQUIRE(mt >= 1 && nb >= 1 && tail_ct >= 1 && tail_ct <= 8 && workers >= 1 && count != nullptr, "trsm_ticket_order: bad shape");
+int tk_order_export(int mt, int nb, int tail_ct, int backward, int workers, int merged, int queues, int32_t* out, int32_t* queue_of, int64_t cap,
+                    int64_t* count) {
+    NNGP_REQUIRE(mt >= 1 && nb >= 1 && tail_ct >= 1 && tail_ct <= 8 && workers >= 1 && count != nullptr && (queues == 1 || queues == kMaxQ),
+                 "trsm_ticket_order: bad shape");
     std::vector<int4> items;
-    tk_build_order(mt, nb, tail_ct, backward != 0, workers, merged != 0, items);
+    std::vector<int> qof;
+    tk_build_order(mt, nb, tail_ct, backward != 0, workers, merged != 0, items, queues, &qof);
     *count = (int64_t)items.size();
     if (out != nullptr) {
         NNGP_REQUIRE((int64_t)items.size() <= cap, "trsm_ticket_order: %lld items, room for %lld", (long long)items.size(), (long long)cap);
         for (size_t i = 0; i < items.size(); ++i) {
             out[4 * i] = items[i].x; out[4 * i + 1] = items[i].y; out[4 * i + 2] = items[i].z; out[4 * i + 3] = items[i].w;
+            if (queue_of != nullptr) queue_of[i] = qof[i];
         }
     }
     return 0;
@@ -1130,11 +1199,26 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
         // a new shape (the first solve, or another batch size): the device may still read the old tables
         NNGP_HIP_CHECK(hipDeviceSynchronize());
         for (int dir = 0; dir < 2; ++dir) {
-            tk_build_order(mt, nb, tail_ct, dir == 1, tk->workers, tk->w_ready[dir], tk->host_items[dir]);
+            std::vector<int4> order;
+            std::vector<int> qof;
+            // (eight tables only for shapes whose launches fill the chip: every XCD then has workgroups drawing from its table)
+            const int nq = (tk->nq == kMaxQ && (int64_t)mt * nb >= 32) ? kMaxQ : 1;
+            tk->nq_dir[dir] = nq;
+            tk_build_order(mt, nb, tail_ct, dir == 1, tk->workers, tk->w_ready[dir], order, nq, &qof);
             tk->key_merged[dir] = (int)tk->w_ready[dir];
-            NNGP_REQUIRE((int64_t)tk->host_items[dir].size() <= tk->items_cap, "tk_solve: item table overflow");
-            tk->n_items[dir] = (int)tk->host_items[dir].size();
-            NNGP_HIP_CHECK(hipMemcpy(tk->items[dir], tk->host_items[dir].data(), sizeof(int4) * tk->host_items[dir].size(), hipMemcpyHostToDevice));
+            NNGP_REQUIRE((int64_t)order.size() <= tk->items_cap, "tk_solve: item table overflow");
+            // the queues' tables one behind the other, each in the global start order
+            std::vector<int4>& tab = tk->host_items[dir];
+            tab.clear();
+            tab.reserve(order.size());
+            for (int q = 0; q < nq; ++q) {
+                tk->q_off[dir][q] = (int)tab.size();
+                for (size_t i = 0; i < order.size(); ++i)
+                    if (qof[i] == q) tab.push_back(order[i]);
+            }
+            for (int q = nq; q <= kMaxQ; ++q) tk->q_off[dir][q] = (int)tab.size();
+            tk->n_items[dir] = (int)tab.size();
+            NNGP_HIP_CHECK(hipMemcpy(tk->items[dir], tab.data(), sizeof(int4) * tab.size(), hipMemcpyHostToDevice));
         }
         tk->key_mt = mt; tk->key_nb = nb; tk->key_tail = tail_ct;
     }
@@ -1153,6 +1237,8 @@ int tk_solve(TrsmTickets* tk, float* b, int64_t ldb, int64_t m, int64_t np, cons
     P.r_stride = tk->m_cap;
     P.items = tk->items[dir];
     P.n_items = tk->n_items[dir];
+    P.nq = tk->nq_dir[dir];
+    for (int q = 0; q <= kMaxQ; ++q) P.q_off[q] = tk->q_off[dir][q];
     P.sync = tk->sync;
     P.mt = mt; P.nb = nb; P.ctiles = (nb - 1) * 8 + tail_ct; P.tail_ct = tail_ct;
     P.l_iscale = 1.0f / sw.scale;

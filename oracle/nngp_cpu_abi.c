@@ -356,6 +356,7 @@ int nngp_model_residual_floor(nngp_model* m, double* ratio, int32_t* distrusted)
 int nngp_model_residual_timer(nngp_model* m, int32_t enable) { (void)m; (void)enable; NOT_HERE("nngp_model_residual_timer"); }
 int nngp_model_residual_timer_read(nngp_model* m, int64_t* launches, double* ms_total, double* flops_total, double* int8_ops_total) { (void)m; (void)launches; (void)ms_total; (void)flops_total; (void)int8_ops_total; NOT_HERE("nngp_model_residual_timer_read"); }
 int nngp_trsm_ticket_order(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged, int32_t* items, int64_t cap, int64_t* count) { (void)row_tiles; (void)block_cols; (void)tail_tiles; (void)backward; (void)workers; (void)merged; (void)items; (void)cap; (void)count; NOT_HERE("nngp_trsm_ticket_order"); }  /* the host build solves by plain substitution */
+int nngp_trsm_ticket_queues(int32_t row_tiles, int32_t block_cols, int32_t tail_tiles, int32_t backward, int32_t workers, int32_t merged, int32_t queues, int32_t* items, int32_t* queue_of, int64_t cap, int64_t* count) { (void)row_tiles; (void)block_cols; (void)tail_tiles; (void)backward; (void)workers; (void)merged; (void)queues; (void)items; (void)queue_of; (void)cap; (void)count; NOT_HERE("nngp_trsm_ticket_queues"); }
 int nngp_model_reserve(nngp_model* m, int64_t rows, int32_t cov_mode) { (void)rows; (void)cov_mode; return m != NULL ? 0 : -2; }  /* the host build allocates per call */
 int64_t nngp_alloc_count(void) { return 0; }
 int nngp_model_trsm_timer(nngp_model* m, int32_t enable) { (void)m; (void)enable; NOT_HERE("nngp_model_trsm_timer"); }

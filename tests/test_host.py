@@ -413,6 +413,122 @@ def test_persistent_solve_ticket_tables_only_wait_on_lower_tickets(mt, nb, tail,
     assert lib.nngp_trsm_ticket_order(0, 4, 8, 0, 512, 1, None, 0, ctypes.byref(count)) != 0
 
 
+class _TicketState:
+    """The kernel's counters (csrc/trsm_tickets.hip) for the draw-protocol test: `ready` is the wait condition an item polls,
+    `apply` what its completion publishes."""
+    KQ = 4
+
+    def __init__(self, mt, nb, tail, backward):
+        self.mt, self.nb, self.tail, self.backward = mt, nb, tail, backward
+        self.ctiles = (nb - 1) * 8 + tail
+        self.xd = np.zeros((mt, nb), np.int64); self.xs = np.zeros((mt, nb), np.int64); self.bs = np.zeros((mt, nb), np.int64)
+        self.up = np.zeros((mt, self.ctiles), np.int64)
+
+    def ct(self, J):
+        return self.tail if J == self.nb - 1 else 8
+
+    def pos(self, J):
+        return self.nb - 1 - J if self.backward else J
+
+    def _update_targets(self, item):
+        word, r, cq, J = item
+        typ, npan = word & 15, (word >> 4) & 15
+        rows = [r] if typ in (3, 5) else [2 * r, 2 * r + 1]
+        cols = [cq] if typ in (3, 5) else [2 * cq, 2 * cq + 1]
+        first = J if typ == 5 else (J + npan - 1 if self.backward else J - npan + 1)
+        return typ, npan, rows, cols, first
+
+    def ready(self, item):
+        word, r, cq, J = item
+        typ = word & 15
+        if typ in (3, 4, 5):
+            typ, npan, rows, cols, first = self._update_targets(item)
+            src = self.bs if typ == 5 else self.xs
+            return all(src[rr, J] == self.KQ and all(self.up[rr, cc] == self.pos(first) for cc in cols) for rr in rows)
+        if typ == 1:
+            return self.bs[r, J] == self.KQ
+        if typ == 2:
+            return self.xd[r, J] == self.ct(J)
+        return all(self.up[r, c] == self.pos(J) for c in range(8 * J, 8 * J + self.ct(J)))
+
+    def apply(self, item):
+        word, r, cq, J = item
+        typ = word & 15
+        if typ in (3, 4, 5):
+            typ, npan, rows, cols, first = self._update_targets(item)
+            for rr in rows:
+                for cc in cols:
+                    self.up[rr, cc] += npan
+        elif typ == 1:
+            self.xd[r, J] += 1
+        elif typ == 2:
+            self.xs[r, J] += 1
+        else:
+            self.bs[r, J] += 1
+
+
+@pytest.mark.parametrize("mt,nb,tail", [(8, 32, 8), (8, 8, 8), (4, 16, 8), (29, 11, 5), (16, 6, 8), (3, 5, 2), (1, 3, 8)])
+def test_persistent_solve_queues_drain_whoever_draws_from_them(mt, nb, tail):
+    """On MI355X the table is eight tables, one per XCD (nngp_trsm_ticket_queues): a workgroup draws from the table of the XCD it runs
+    on and, once that has run out, from the others.  What keeps such a launch from hanging: (1) the global start order of the host's
+    schedule has every item behind its dependencies (the single-table property), (2) every table holds its items in that order.
+    Then the earliest unfinished item is at the head of its table and the workgroups drawing there hold nothing later than it.  The
+    test checks (1) and (2) and then RUNS the draw protocol -- any number of workgroups per XCD, at least one (the product uses the
+    eight tables only for launches of >= 224 workgroups, which the hardware deals round-robin over the XCDs; an XCD without any would
+    end in the kernel's bounded waits and the step-by-step fallback), items finishing in random order -- to the end."""
+    lib = _lib.load()
+    rng = np.random.default_rng(mt * 1000 + nb * 10 + tail)
+    for backward, merged in ((0, 0), (1, 0), (0, 1)):
+        count = ctypes.c_int64(0)
+        assert lib.nngp_trsm_ticket_queues(mt, nb, tail, backward, 256, merged, 8, None, None, 0, ctypes.byref(count)) == 0, lib.nngp_last_error()
+        buf = np.zeros((count.value, 4), np.int32)
+        qof = np.zeros(count.value, np.int32)
+        assert lib.nngp_trsm_ticket_queues(mt, nb, tail, backward, 256, merged, 8, buf.ctypes.data_as(ctypes.c_void_p),
+                                           qof.ctypes.data_as(ctypes.c_void_p), count.value, ctypes.byref(count)) == 0, lib.nngp_last_error()
+        items = [tuple(int(v) for v in row) for row in buf]
+        n, _ = _replay_ticket_table(items, mt, nb, tail, bool(backward))   # (1)
+        assert n == count.value and qof.min() >= 0 and qof.max() < 8
+        if mt >= 8:
+            assert len(set(qof.tolist())) == 8, "a shape with four pairs of row tiles leaves a queue empty"
+        # the bulk items of one pair of row tiles sit in the queues of that pair only
+        for (word, r, cq, J), q in zip(items, qof):
+            if word & 15 == 4 and mt // 2 in (1, 2, 4, 8):
+                per = 8 // (mt // 2)
+                assert r * per <= q < (r + 1) * per, "a bulk item outside the queues of its pair of row tiles"
+        tables = [[i for i in range(n) if qof[i] == q] for q in range(8)]   # (2): by construction of the device tables (tk_solve)
+        for workers_per_q in ([1] * 8, [4] * 8, [32] * 8, [2, 1, 3, 1, 1, 5, 1, 2]):
+            state = _TicketState(mt, nb, tail, bool(backward))
+            head = [0] * 8
+            held = []   # (item index, home queue of the worker)
+            idle = [q for q in range(8) for _ in range(workers_per_q[q])]
+            done = 0
+
+            def draw(q):
+                for k in range(8):
+                    qq = (q + k) % 8
+                    if head[qq] < len(tables[qq]):
+                        head[qq] += 1
+                        return tables[qq][head[qq] - 1]
+                return None
+
+            while done < n:
+                still_idle = []
+                for q in idle:
+                    i = draw(q)
+                    if i is None:
+                        still_idle.append(q)
+                    else:
+                        held.append((i, q))
+                idle = still_idle
+                runnable = [k for k, (i, q) in enumerate(held) if state.ready(items[i])]
+                assert runnable, ("the launch would hang", mt, nb, tail, backward, merged, workers_per_q, done, n)
+                k = runnable[int(rng.integers(len(runnable)))]
+                i, q = held.pop(k)
+                state.apply(items[i])
+                done += 1
+                idle.append(q)
+
+
 def test_persistent_solve_kernel_has_no_loop_the_threads_of_a_wave_leave_apart(tmp_path):
     """The first GPU run of csrc/trsm_tickets.hip hung with every workgroup holding its first ticket: hipcc had threaded thread 0's
     path (publish -> next ticket) across the back edge of the item loop, which turned the rest of the loop into an INNER loop that the
