@@ -1220,3 +1220,29 @@ def test_a_lost_completion_in_a_persistent_solve_costs_an_error_code_not_the_gpu
     assert np.linalg.norm(X - Xref) <= 2e-3 * np.linalg.norm(Xref)
     assert np.linalg.norm(good - Xref) <= 2e-3 * np.linalg.norm(Xref)
     model.close()
+
+
+def test_persistent_solves_with_one_table_per_xcd_return_the_same_bits():
+    """Round 5, optional form (NNGP_TK_QUEUES=8, read when a model is created): the item table of a persistent solve as eight tables,
+    one per XCD, a workgroup drawing from the table of the XCD it runs on.  The arithmetic of every tile and the order of the updates
+    a tile receives are those of the single table, so both halves of the solve must come out bit for bit the same -- and the launch
+    must drain (tests/test_host.py proves the protocol; here it runs on the chip)."""
+    n, rows = 9300, 1024
+    x, y = synth.synthetic_queries(n, 24, seed=52)
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal((rows, n)).astype(np.float32)
+    out = []
+    for queues in ("1", "8"):
+        os.environ["NNGP_TK_QUEUES"] = queues
+        try:
+            model = GPModel(n, 24, [1.0, 1.0], [0.0, 0.0], diag_reg=1e-3).fit(x, y)
+        finally:
+            del os.environ["NNGP_TK_QUEUES"]
+        t0 = time.perf_counter()
+        fwd = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev())).cpu().numpy()
+        both = model.apply_factor(torch.from_numpy(B.copy()).to(G.dev()), both_halves=True).cpu().numpy()
+        assert time.perf_counter() - t0 < 5.0
+        out.append((fwd, both))
+        model.close()
+    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
