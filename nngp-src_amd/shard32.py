@@ -15,7 +15,7 @@ budgets, and by the repo's own cost model slower than rebuilding the kernel loca
   (``nngp_model_apply_factor``), the ranks all-gather those float32 rows Z (4 M N bytes in all), every rank multiplies ALL of them by
   its own kernel rows -- ``(Z A)[:, rows of g] = Z K[rows of g, :]^T``, K symmetric: the float64 residual product sharded by the rows a
   rank holds -- and one all-gather of the M x N/G blocks returns the products; the level-1 variance formula of the single-GPU path
-  follows locally (``k^T A^-1 k = z.(k + r) + |L^-1 r|^2``, csrc/api.hip).
+  follows locally (``k^T A^-1 k = z.(k + r) + |L^-1 r|^2``, csrc/api_predict.hip).
 
 The tile arithmetic sits behind a small ``ops`` interface (``HipRowOps``: the C ABI on the MI355X; the tests also run the distribution
 logic with a NumPy stand-in on CPU ranks).  UNMEASURED ON HARDWARE: no multi-GPU box was available to rounds 1-4; rehearsed with gloo
