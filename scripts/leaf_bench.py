@@ -1,5 +1,5 @@
 """Back-to-back Cholesky leaves (128 x 128, one workgroup each) on a warm chip: microseconds per launch, by HIP events.
-scripts/leaf_bench.py [form knob 3] [mode knob 6]"""
+scripts/leaf_bench.py [3]  (3: round 4's column phases, A/B)"""
 import os; os.environ.setdefault("NNGP_KNOBS", "1")
 import sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,6 @@ base = torch.randn((nb, n, n), device=G.dev())
 spd = base @ base.transpose(1, 2) / n + torch.eye(n, device=G.dev()) * 2.0
 dinv = torch.empty((nb, 128, 128), device=G.dev()); cl = torch.zeros(1, dtype=torch.int32, device=G.dev())
 if len(sys.argv) > 1: _lib.check(lib.nngp_debug_set(3, int(sys.argv[1])))
-if len(sys.argv) > 2: _lib.check(lib.nngp_debug_set(6, int(sys.argv[2])))
 a = spd.clone()
 out = []
 for rep in range(6):
